@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""Headline benchmark: RGB-D frame pairs/s of the fused back-project + warp +
+residual-reduce kernel at 640x480, batch 64 per GPU (BASELINE.json configs[1]),
+one process per GPU.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step is one call of slamhip_pair_loss_fused over one batch of 64 synthetic
+frame pairs that already sit in HBM.  The batches rotate through several
+distinct buffers (together larger than the 256 MiB Infinity Cache), so every
+step streams its frames from HBM.  Frame pairs are independent: each rank owns
+its own pairs and no data-path collective runs (weak scaling); the only
+collective is the max-over-ranks of the elapsed time.
+
+Rank 0 prints one JSON line; `roofline` prices the fused kernel against the HBM
+peak with the algorithmic bytes (10 B per pixel: uint16 depth + 3 x uint8 colour
+of both frames), `cpu_baseline` times the C restatement of the oracle on the
+host (one core) on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+H, W = 480, 640
+BYTES_PER_PIXEL = 10                      # depth u16 + rgb u8x3, both frames
+BYTES_PER_PAIR = H * W * BYTES_PER_PIXEL  # 3,072,000
+HBM_PEAK_GBS = 8000.0                     # MI355X HBM3E spec peak
+METRIC = "RGB-D frame pairs/sec @640×480 (warp+loss+encoder), 1/2/4/8 GPU, % HBM roofline"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step")
+    ap.add_argument("--buffers", type=int, default=4, help="distinct HBM batches the steps rotate through")
+    ap.add_argument("--factor", type=float, default=1.0, help="depth divisor (1 = reference, 5000 = metric)")
+    ap.add_argument("--depth", default="plane", choices=["plane", "noise"])
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline (0 = skip)")
+    return ap.parse_args()
+
+
+def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s):
+    """C restatement of the oracle, one host core, bounded sample."""
+    from oracle import c_oracle
+    n = min(8, d1.shape[0])
+    args = (d1[:n], c1[:n], d2[:n], c2[:n], rel[:n], K, factor)
+    c_oracle.pair_loss(*args)  # touch pages / load the library
+    done, t0 = 0, time.perf_counter()
+    while True:
+        sums, counts = c_oracle.pair_loss(*args)
+        done += n
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return dict(value=done / el, unit="frame pairs/s", cores=1, kind="port",
+                sample="%d pairs (the first %d pairs of rank 0's batch, repeated) in %.1f s, "
+                       "oracle/slam_oracle.c single-threaded" % (done, n, el)), sums, counts
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist = None
+        torch.cuda.set_device(0)
+    if a.gpus != world and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+
+    from slam_amd import frame_pairs as fp
+    from slam_amd.utils import synthetic as syn
+
+    B = a.batch
+    K = fp.intrinsics(1)
+    seed = 1000 * rank
+    gt = syn.pose_pairs(B, seed=seed + 3)
+    d1 = syn.depth_frames(B, H, W, seed=seed + 1, kind=a.depth)
+    d2 = syn.depth_frames(B, H, W, seed=seed + 2, kind=a.depth)
+    c1 = syn.rgb_frames(B, H, W, seed=seed + 1, kind="noise")
+    c2 = syn.rgb_frames(B, H, W, seed=seed + 2, kind="noise")
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gt_d = torch.from_numpy(gt).to(dev)
+    rel = fp.relative_pose(gt_d[:, 0].contiguous(), gt_d[:, 1].contiguous()).reshape(B, 1, 4, 4)
+    bufs = []
+    for i in range(max(1, a.buffers)):
+        # the same pairs in a rotated order, each copy in its own HBM allocation
+        bufs.append([torch.from_numpy(np.roll(x, i, axis=0)).to(dev) for x in (d1, c1, d2, c2)] +
+                    [rel.roll(i, 0).contiguous()])
+    sums = torch.empty((B, 1, 4), dtype=torch.float64, device=dev)
+    counts = torch.empty((B, 1, 4), dtype=torch.int32, device=dev)
+
+    def step(i):
+        x = bufs[i % len(bufs)]
+        fp.pair_loss(x[0], x[1], x[2], x[3], x[4], K, a.factor, out=(sums, counts))
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ev[i][0].record()
+        step(i)
+        ev[i][1].record()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launch_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+
+    if rank == 0:
+        # the last step ran on bufs[(steps-1) % nb]; check its first pair against the C oracle
+        last = bufs[(a.steps - 1) % len(bufs)] if a.steps else bufs[0]
+        cb = None
+        verified = None
+        if a.cpu_seconds > 0:
+            host = [t.cpu().numpy() for t in last]
+            cb, o_s, o_c = cpu_baseline(host[0], host[1], host[2], host[3], host[4], K, a.factor, a.cpu_seconds)
+            n = o_s.shape[0]
+            got_c = counts[:n].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            verified = bool(np.array_equal(got_c, o_c.astype(np.int64)) and
+                            np.allclose(sums[:n].cpu().numpy(), o_s, rtol=1e-4))
+        pairs = world * B * a.steps
+        achieved = BYTES_PER_PAIR * B / (launch_ms * 1e-3) / 1e9
+        line = {
+            "metric": METRIC,
+            "value": pairs / elapsed,
+            "unit": "frame pairs/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": elapsed / max(1, a.steps) * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic 640x480 depth+RGB pairs, batch %d per GPU, "
+                                   "backproject+warp+loss fused (k=1 neighbour), %s depth, factor %g"
+                                   % (B, a.depth, a.factor),
+                       "pairs_per_gpu_per_step": B, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "pair_loss_fused_kernel", "launch_ms": launch_ms,
+                         "algorithmic_bytes_per_launch": BYTES_PER_PAIR * B},
+            "cpu_baseline": cb,
+            "verified_against_oracle": verified,
+        }
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,132 @@
+/*
+ * slamhip - C ABI of the MI355X (gfx950) RGB-D frame-pair hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain pointers and sizes and returns
+ * 0 on success or a negative SLAMHIP_E_* code (never throws, never aborts);
+ * slamhip_last_error() gives the message of the calling thread's last failure.
+ *
+ * Pointer conventions
+ *   - "host" functions take host pointers and run on the CPU (pose maths).
+ *   - every other function takes DEVICE pointers (hipMalloc'd / torch CUDA
+ *     tensors), is asynchronous on `stream` (a hipStream_t passed as void*,
+ *     NULL = the null stream) and never allocates or frees device memory.
+ *   - images are contiguous row-major: depth [B,H,W] uint16, colour
+ *     [B,H,W,3] uint8; neighbour frames [B,k,H,W(,3)]; poses [B,k,16] float64
+ *     (row-major 4x4).  K = {fx, fy, cx, cy}; `factor` is the depth divisor
+ *     (1 in the reference, 5000 for metric TUM depth).
+ *
+ * The reference (sanjeevk42/SLAM) is pure Python and has no FFI of its own; the
+ * file:line cited at each declaration is the Python function whose arithmetic
+ * the entry point replaces.  All coordinate arithmetic is IEEE float64 in the
+ * reference's operation order (no contraction), so masks, counts and pixel
+ * indices are bit-identical to the reference's numpy results.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMHIP_OK 0
+#define SLAMHIP_E_ARG (-1)      /* bad argument (null pointer, non-positive size, ...) */
+#define SLAMHIP_E_HIP (-2)      /* a HIP runtime call or kernel launch failed */
+#define SLAMHIP_E_SIZE (-3)     /* size beyond what the entry point supports */
+
+/* number of reduced quantities per (pair, neighbour) */
+#define SLAMHIP_NSUMS 4         /* sum|r_photo|, sum r_photo^2, sum|r_geo|, sum r_geo^2 */
+#define SLAMHIP_NCOUNTS 4       /* n_valid0, n_inb, n_warp, n_geo */
+
+/* bits of the per-pixel mask byte written by slamhip_warp_materialize */
+#define SLAMHIP_M_VALID0 1      /* x,y,z all != 0           (test_import.py:156) */
+#define SLAMHIP_M_INB 2         /* 0<=u<=W and 0<=v<=H      (test_import.py:174) */
+#define SLAMHIP_M_WARP 4        /* 0<=u<=W-1, 0<=v<=H-1, d>0 (bilinear taps exist) */
+#define SLAMHIP_M_GEO 8         /* M_WARP and all four depth-2 taps != 0 */
+
+const char* slamhip_last_error(void);
+int slamhip_version(void);
+
+/* ---- host: pose / label maths (float64, reference quirks kept) ------------ */
+
+/* slam/preprocess/test_import.py:18-47 - [tx ty tz qx qy qz qw] (float32 rows, as
+ * the callers cast them at :199) -> row-major 4x4 float64; q is not normalised. */
+int slamhip_quat_to_transformation(const float* gt7, int n, double* T4x4);
+
+/* test_import.py:80-86 - [R^T, -R^T t; 0 1]. */
+int slamhip_inverse_trans(const double* T4x4, int n, double* inv4x4);
+
+/* test_import.py:50-77 (clamp=0) / slam/network/model_input.py:46-76 (clamp=1):
+ * SO(3) log + the reference's translation solve; guards give zeros, an exact
+ * identity rotation gives NaN. */
+int slamhip_trans_to_twist(const double* T4x4, int n, int clamp, double* twist6);
+
+/* test_import.py:89-110 (guard=1) / model_input.py:88-106 (guard=0). */
+int slamhip_twist_to_trans(const double* twist6, int n, int guard, double* T4x4);
+
+/* test_import.py:199-207,219 for n independent pairs: rel = inv(T(a)) . T(b) and
+ * twist = trans_to_twist(rel).  rel4x4 and twist6 may each be NULL. */
+int slamhip_pose_batch(const float* gt7_a, const float* gt7_b, int n, int clamp,
+                       double* rel4x4, double* twist6);
+
+/* ---- device: relative pose for ground truth already resident in HBM ------- */
+
+/* test_import.py:199-207 - gt7_a/gt7_b float32 [n,7] (device) -> rel [n,16] float64. */
+int slamhip_relative_pose_device(const float* gt7_a, const float* gt7_b, int n,
+                                 double* rel4x4, void* stream);
+
+/* ---- device: per-pixel geometry, materialising forms ---------------------- */
+
+/* test_import.py:148-155 dense: xyz [B,H,W,3] (float64 if xyz_f64 else float32,
+ * rounded once from the float64 value) and valid0 [B,H,W] (0/1, the compaction
+ * rule of :156).  Either output may be NULL. */
+int slamhip_backproject(const uint16_t* depth, int B, int H, int W, const double K[4],
+                        double factor, void* xyz, int xyz_f64, uint8_t* valid0, void* stream);
+
+/* test_import.py:159-176 dense: transform xyz by rel (one pose per image,
+ * [B,16]), project to (u,v,d), evaluate the in-image predicate against
+ * dim = [dim_u, dim_v] and count.  xyz [B,H,W,3] must be float64 for
+ * bit-exact parity (xyz_f64=1); valid0 may be NULL (then recomputed from xyz);
+ * rel4x4 may be NULL (no transform: xyz is projected as it is, :163-168 alone).
+ * Outputs (each may be NULL): xyz2 and uvd [B,H,W,3] (float64 if out_f64),
+ * iu_iv int32 [B,H,W,2] = floor(u), floor(v) (saturating, NaN -> INT32_MIN),
+ * inb uint8 [B,H,W], counts uint32 [B,2] = {n_valid0, n_inb} (zeroed on-stream). */
+int slamhip_reproject(const void* xyz, int xyz_f64, const uint8_t* valid0, const double* rel4x4,
+                      const double K[4], double dim_u, double dim_v, int B, int H, int W,
+                      void* xyz2, void* uvd, int out_f64, int32_t* iu_iv, uint8_t* inb,
+                      uint32_t* counts, void* stream);
+
+/* test_import.py:171-176 on an already projected point list: uvd float64 [n,3];
+ * mask uint8 [n] (may be NULL) and count uint32 [1] (zeroed on-stream) of the
+ * points with 0<=u<=dim_u and 0<=v<=dim_v. */
+int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double dim_v, uint8_t* mask,
+                          uint32_t* count, void* stream);
+
+/* ---- device: fused frame-pair kernel (the benchmarked path) --------------- */
+
+/* test_import.py:148-176 + bilinear warp + residual reduction, nothing
+ * materialised.  depth1 [B,H,W], rgb1 [B,H,W,3]: anchor frames; depth2
+ * [B,k,H,W], rgb2 [B,k,H,W,3]: the k neighbour frames of each anchor; rel
+ * [B,k,16].  Outputs: sums float64 [B,k,SLAMHIP_NSUMS], counts uint32
+ * [B,k,SLAMHIP_NCOUNTS]; both are zeroed on-stream before the kernel. */
+int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                            const uint8_t* rgb2, const double* rel4x4, const double K[4],
+                            double factor, int B, int k, int H, int W, double* sums,
+                            uint32_t* counts, void* stream);
+
+/* Same arithmetic as slamhip_pair_loss_fused, per-pixel results written out
+ * (each output may be NULL): warped_rgb float32 [B,k,H,W,3], warped_depth
+ * float32 [B,k,H,W], r_photo float32 [B,k,H,W,3], r_geo float32 [B,k,H,W],
+ * mask uint8 [B,k,H,W] (SLAMHIP_M_* bits), iu_iv int32 [B,k,H,W,2], uvd
+ * float64 [B,k,H,W,3]. */
+int slamhip_warp_materialize(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                             const uint8_t* rgb2, const double* rel4x4, const double K[4],
+                             double factor, int B, int k, int H, int W, float* warped_rgb,
+                             float* warped_depth, float* r_photo, float* r_geo, uint8_t* mask,
+                             int32_t* iu_iv, double* uvd, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

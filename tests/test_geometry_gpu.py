@@ -1,0 +1,265 @@
+"""Parity of the HIP frame-pair kernels (through the C ABI) against the numpy
+oracle and the golden vectors of the reference.  Integer/byte results (masks,
+counts, pixel indices) are compared bit-exactly; float64 coordinates bit-exactly;
+float32 intensities, residuals and the reduced sums within 1e-4 relative (the
+tolerance the task states for fp32 quantities)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import slam_oracle as so
+from slam_amd.utils import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def fp():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from slam_amd import frame_pairs
+    return frame_pairs
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _u32(t):
+    return t.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+
+
+def synth_depth(rs, h, w, zero_frac=0.15):
+    d = rs.randint(2500, 25001, size=(h, w)).astype(np.uint16)
+    d[rs.uniform(size=(h, w)) < zero_frac] = 0
+    return d
+
+
+def test_relative_pose_device_golden(fp, golden_dir):
+    g = np.load(os.path.join(golden_dir, "pose.npz"))
+    rel = fp.relative_pose(_dev(g["gt_a"]), _dev(g["gt_b"])).cpu().numpy()
+    assert np.array_equal(rel, g["rel"])
+
+
+def test_small_golden_dense(fp, golden_dir):
+    g = np.load(os.path.join(golden_dir, "geometry_small.npz"))
+    for i in range(int(g["n_cases"])):
+        k = "g%d_" % i
+        ds = int(g[k + "dataset"])
+        K = fp.intrinsics(ds)
+        depth, rel, dim = g[k + "depth"], g[k + "rel"], g[k + "dim"]
+        xyz, valid0 = fp.backproject(_dev(depth[None]), K)
+        v0 = valid0.cpu().numpy().reshape(-1).astype(bool)
+        assert np.array_equal(xyz.cpu().numpy().reshape(-1, 3)[v0], g[k + "pc"])
+        out = fp.reproject(xyz, _dev(rel[None]), K, dim, valid0=valid0)
+        assert np.array_equal(out["xyz2"].cpu().numpy().reshape(-1, 3)[v0], g[k + "tp"])
+        assert np.array_equal(out["uvd"].cpu().numpy().reshape(-1, 3)[v0], g[k + "uvd"])
+        assert np.array_equal(out["inb"].cpu().numpy().reshape(-1)[v0], g[k + "mask_dim"])
+        c = _u32(out["counts"])[0]
+        assert c[0] == g[k + "pc"].shape[0]
+        assert float(c[1]) / float(c[0]) == float(g[k + "overlap_dim"])
+        # float32 outputs are the float64 values rounded once
+        xyz32, _ = fp.backproject(_dev(depth[None]), K, dtype=torch.float32)
+        assert np.array_equal(xyz32.cpu().numpy(), xyz.cpu().numpy().astype(np.float32))
+
+
+def test_full_frame_golden(fp, golden_dir):
+    g = np.load(os.path.join(golden_dir, "geometry_full.npz"))
+    for ds in (1, 2, 3):
+        k = "f%d_" % ds
+        depth = synth_depth(np.random.RandomState(int(g[k + "seed"])), 480, 640)
+        assert np.array_equal(_sha(depth), g[k + "depth_sha256"])
+        K = fp.intrinsics(ds)
+        xyz, valid0 = fp.backproject(_dev(depth[None]), K)
+        out = fp.reproject(xyz, _dev(g[k + "rel"][None]), K, (640, 480), valid0=valid0)
+        v0 = valid0.cpu().numpy().reshape(-1).astype(bool)
+        pc = xyz.cpu().numpy().reshape(-1, 3)[v0]
+        tp = out["xyz2"].cpu().numpy().reshape(-1, 3)[v0]
+        uvd = out["uvd"].cpu().numpy().reshape(-1, 3)[v0]
+        mask = out["inb"].cpu().numpy().reshape(-1)[v0]
+        assert np.array_equal(_sha(pc), g[k + "pc_sha256"])
+        assert np.array_equal(_sha(tp), g[k + "tp_sha256"])
+        assert np.array_equal(_sha(uvd), g[k + "uvd_sha256"])
+        assert np.array_equal(_sha(mask), g[k + "mask_sha256"])
+        c = _u32(out["counts"])[0]
+        assert c[0] == int(g[k + "n_valid"]) and c[1] == int(g[k + "n_inb"])
+        assert float(c[1]) / float(c[0]) == float(g[k + "overlap"])
+
+
+def test_reference_named_functions(fp, golden_dir):
+    from slam_amd.preprocess import geometry as geo
+    g = np.load(os.path.join(golden_dir, "geometry_small.npz"))
+    for i in (0, 6, 7):
+        k = "g%d_" % i
+        ds = int(g[k + "dataset"])
+        pc = geo._point_cloud(g[k + "depth"], ds)
+        assert np.array_equal(pc, g[k + "pc"])
+        tp = geo._transform_pointcloud(pc, g[k + "rel"])
+        assert np.array_equal(tp, g[k + "tp"])
+        uvd = geo._backtransform_pointcloud(tp, ds)
+        assert np.array_equal(uvd, g[k + "uvd"])
+        assert geo._overlap(uvd, list(g[k + "dim"])) == float(g[k + "overlap_dim"])
+        assert geo._overlap(uvd, [640, 480]) == float(g[k + "overlap_640x480"])
+    p = np.load(os.path.join(golden_dir, "pose.npz"))
+    for i in range(p["gt_a"].shape[0]):
+        assert np.array_equal(geo._quat_to_transformation(p["gt_a"][i]), p["T_a"][i])
+        tw = geo._trans_to_twist(p["rel"][i])
+        assert (tw.ndim, tw.size) == tuple(p["twist_ndim_size"][i])
+        np.testing.assert_allclose(np.asarray(tw).reshape(6), p["twist"][i], rtol=1e-11, atol=1e-13, equal_nan=True)
+
+
+def test_get_data_facade(fp, golden_dir):
+    from slam_amd.preprocess import geometry as geo
+    g = np.load(os.path.join(golden_dir, "get_data.npz"))
+    assoc, gt, depths = g["assoc"], g["gt"], g["depths"]
+    index = {assoc[i, 3]: i for i in range(assoc.shape[0])}
+    tw, rp, dp = geo._get_data(assoc, gt, 1000)
+    np.testing.assert_allclose(tw, g["a_twist"], rtol=1e-11, atol=1e-13)
+    assert list(rp) == list(g["a_rgb"]) and list(dp) == list(g["a_depth"])
+    tw, rp, dp = geo._get_data(assoc, gt, 4, 0.0, 2, rng=np.random.RandomState(int(g["b_seed"])))
+    np.testing.assert_allclose(tw, g["b_twist"], rtol=1e-11, atol=1e-13)
+    assert list(rp) == list(g["b_rgb"])
+    for tag in ("c", "d"):
+        tw, rp, dp = geo._get_data(assoc, gt, 1000, float(g[tag + "_thr"]), 1,
+                                   read_depth=lambda p: depths[index[p]])
+        np.testing.assert_allclose(tw, g[tag + "_twist"], rtol=1e-11, atol=1e-13)
+        assert list(rp) == list(g[tag + "_rgb"]) and list(dp) == list(g[tag + "_depth"])
+
+
+def _pairs(B, k, H, W, seed, depth_kind="plane", rgb_kind="smooth", max_deg=3.0, max_t=0.05):
+    gt = syn.pose_pairs(B * k, seed=seed, max_t=max_t, max_deg=max_deg)
+    d1 = syn.depth_frames(B, H, W, seed=seed, kind=depth_kind)
+    c1 = syn.rgb_frames(B, H, W, seed=seed, kind=rgb_kind)
+    d2 = syn.depth_frames(B * k, H, W, seed=seed + 1, kind=depth_kind).reshape(B, k, H, W)
+    c2 = syn.rgb_frames(B * k, H, W, seed=seed + 1, kind=rgb_kind).reshape(B, k, H, W, 3)
+    rel = np.stack([so.relative_pose(so.quat_to_transformation(gt[i, 0]), so.quat_to_transformation(gt[i, 1]))
+                    for i in range(B * k)]).reshape(B, k, 4, 4)
+    return d1, c1, d2, c2, rel
+
+
+def _check_warp(fp, d1, c1, d2, c2, rel, K, factor):
+    o = fp.warp(_dev(d1), _dev(c1), _dev(d2), _dev(c2), _dev(rel), K, factor)
+    o = {n: t.cpu().numpy() for n, t in o.items()}
+    B, k = rel.shape[0], rel.shape[1]
+    for b in range(B):
+        for j in range(k):
+            P = so.warp_pair(d1[b], c1[b], d2[b, j], c2[b, j], rel[b, j], K, factor)
+            m = o["mask"][b, j]
+            assert np.array_equal((m & 1) != 0, P["valid0"])
+            assert np.array_equal((m & 2) != 0, P["inb"])
+            assert np.array_equal((m & 4) != 0, P["warp_valid"])
+            assert np.array_equal((m & 8) != 0, P["geo_valid"])
+            assert np.array_equal(o["iu_iv"][b, j, ..., 0], P["iu"])
+            assert np.array_equal(o["iu_iv"][b, j, ..., 1], P["iv"])
+            assert np.array_equal(o["uvd"][b, j], P["uvd"], equal_nan=True)
+            np.testing.assert_allclose(o["warped_rgb"][b, j], P["warped_rgb"], rtol=RTOL, atol=1e-4)
+            np.testing.assert_allclose(o["warped_depth"][b, j], P["warped_depth"], rtol=RTOL, atol=1e-4)
+            np.testing.assert_allclose(o["r_photo"][b, j], P["r_photo"], rtol=RTOL, atol=1e-3)
+            np.testing.assert_allclose(o["r_geo"][b, j], P["r_geo"], rtol=RTOL, atol=1e-2)
+    return o
+
+
+def _check_fused(fp, d1, c1, d2, c2, rel, K, factor):
+    sums, counts = fp.pair_loss(_dev(d1), _dev(c1), _dev(d2), _dev(c2), _dev(rel), K, factor)
+    want_s, want_c = so.pair_loss(d1, c1, d2, c2, rel, K, factor)
+    assert np.array_equal(_u32(counts), want_c.astype(np.int64))
+    np.testing.assert_allclose(sums.cpu().numpy(), want_s, rtol=RTOL, atol=1e-6)
+    return sums, counts
+
+
+@pytest.mark.parametrize("H,W,factor,dk,ck", [
+    (48, 64, 1.0, "noise", "noise"),
+    (48, 64, 5000.0, "plane", "smooth"),
+    (37, 53, 1.0, "plane", "noise"),       # ragged: W not a multiple of 8, partial tiles
+    (16, 128, 1.0, "plane", "smooth"),     # exactly one tile
+    (5, 7, 1.0, "noise", "noise"),
+])
+def test_warp_and_fused_small(fp, H, W, factor, dk, ck):
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    d1, c1, d2, c2, rel = _pairs(3, 2, H, W, seed=H * 1000 + W, depth_kind=dk, rgb_kind=ck)
+    _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+    _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+
+
+@pytest.mark.parametrize("factor,dk,ck,deg", [
+    (1.0, "plane", "smooth", 3.0),
+    (1.0, "noise", "noise", 3.0),
+    (5000.0, "plane", "smooth", 3.0),      # metric depth: parallax, LDS window per tile
+    (5000.0, "noise", "noise", 3.0),       # per-pixel random depth: scattered taps, fallback path
+    (1.0, "plane", "noise", 40.0),         # large rotation: most points leave the image
+])
+def test_warp_and_fused_full_frame(fp, factor, dk, ck, deg):
+    K = fp.intrinsics(1)
+    d1, c1, d2, c2, rel = _pairs(2, 1, 480, 640, seed=int(deg * 7 + factor), depth_kind=dk, rgb_kind=ck, max_deg=deg)
+    _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+    _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+
+
+def test_edge_cases(fp):
+    K = fp.intrinsics(1)
+    H, W = 32, 64
+    d1, c1, d2, c2, rel = _pairs(2, 1, H, W, seed=5)
+    # all-zero depth: nothing valid
+    z = np.zeros_like(d1)
+    s, c = _check_fused(fp, z, c1, d2, c2, rel, K, 1.0)
+    assert not _u32(c).any() and not s.cpu().numpy().any()
+    # identity pose
+    eye = np.tile(np.eye(4), (2, 1, 1, 1))
+    _check_warp(fp, d1, c1, d2, c2, eye, K, 1.0)
+    _check_fused(fp, d1, c1, d2, c2, eye, K, 1.0)
+    # pose that puts every point behind the camera / at z' == 0 (inf, NaN coordinates)
+    flip = eye.copy()
+    flip[:, :, 2, 2] = -1.0
+    _check_warp(fp, d1, c1, d2, c2, flip, K, 1.0)
+    _check_fused(fp, d1, c1, d2, c2, flip, K, 1.0)
+    zero = eye.copy()
+    zero[:, :, 2, 2] = 0.0
+    _check_warp(fp, d1, c1, d2, c2, zero, K, 1.0)
+    _check_fused(fp, d1, c1, d2, c2, zero, K, 1.0)
+    # maximum depth values
+    full = np.full_like(d1, 65535)
+    _check_fused(fp, full, c1, full[:, None], c2, rel, K, 1.0)
+    # empty batch
+    s, c = fp.pair_loss(_dev(d1[:0]), _dev(c1[:0]), _dev(d2[:0]), _dev(c2[:0]), _dev(rel[:0]), K, 1.0)
+    assert s.shape[0] == 0 and c.shape[0] == 0
+
+
+def test_fused_equals_materialised_at_bench_size(fp):
+    """Batch 64 at 640x480 (the benchmark configuration): the oracle would take
+    minutes, so check the size-independent property that the fused reduction
+    equals the reduction of the materialised per-pixel outputs, counts exactly."""
+    K = fp.intrinsics(1)
+    B = 64
+    d1 = _dev(syn.depth_frames(B, 480, 640, seed=1, kind="plane"))
+    d2 = _dev(syn.depth_frames(B, 480, 640, seed=2, kind="plane"))
+    c1 = _dev(syn.rgb_frames(B, 480, 640, seed=1, kind="noise"))
+    c2 = _dev(syn.rgb_frames(B, 480, 640, seed=2, kind="noise"))
+    gt = _dev(syn.pose_pairs(B, seed=3))
+    rel = fp.relative_pose(gt[:, 0].contiguous(), gt[:, 1].contiguous()).reshape(B, 1, 4, 4)
+    sums, counts = fp.pair_loss(d1, c1, d2, c2, rel, K, 1.0)
+    cnt = np.zeros((B, 4), np.int64)
+    ref = np.zeros((B, 4))
+    for lo in range(0, B, 8):
+        sl = slice(lo, lo + 8)
+        o = fp.warp(d1[sl], c1[sl], d2[sl], c2[sl], rel[sl], K, 1.0)
+        m = o["mask"][:, 0]
+        for q in range(4):
+            cnt[sl, q] = ((m >> q) & 1).sum(dim=(1, 2)).cpu().numpy()
+        rp = o["r_photo"][:, 0].double()
+        rg = o["r_geo"][:, 0].double()
+        ref[sl, 0] = rp.abs().sum(dim=(1, 2, 3)).cpu().numpy()
+        ref[sl, 1] = (rp * rp).sum(dim=(1, 2, 3)).cpu().numpy()
+        ref[sl, 2] = rg.abs().sum(dim=(1, 2)).cpu().numpy()
+        ref[sl, 3] = (rg * rg).sum(dim=(1, 2)).cpu().numpy()
+    assert np.array_equal(_u32(counts)[:, 0], cnt)
+    np.testing.assert_allclose(sums.cpu().numpy()[:, 0], ref, rtol=1e-5)
+    assert (cnt[:, 2] > 0.5 * 480 * 640).all()  # TUM-like motion keeps most pixels in view
