@@ -24,6 +24,7 @@
 #ifndef SLAMHIP_H
 #define SLAMHIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -105,15 +106,25 @@ int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double d
 
 /* ---- device: fused frame-pair kernel (the benchmarked path) --------------- */
 
+/* Bytes of workspace slamhip_pair_loss_fused needs for a batch of B anchors with
+ * k neighbours each (64 bytes per pair).  No counterpart in the reference. */
+size_t slamhip_pair_loss_workspace_bytes(int B, int k);
+
 /* test_import.py:148-176 + bilinear warp + residual reduction, nothing
  * materialised.  depth1 [B,H,W], rgb1 [B,H,W,3]: anchor frames; depth2
  * [B,k,H,W], rgb2 [B,k,H,W,3]: the k neighbour frames of each anchor; rel
  * [B,k,16].  Outputs: sums float64 [B,k,SLAMHIP_NSUMS], counts uint32
- * [B,k,SLAMHIP_NCOUNTS]; both are zeroed on-stream before the kernel. */
+ * [B,k,SLAMHIP_NCOUNTS], fully overwritten.
+ * `workspace` is device memory of at least slamhip_pair_loss_workspace_bytes(B,k)
+ * bytes, 8-byte aligned, that the CALLER ZERO-FILLS ONCE after allocating it;
+ * every successful call leaves it zero-filled again, so one launch and no
+ * memset runs on the stream.  Calls that share a workspace must not overlap
+ * (use one workspace per stream). */
 int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
                             const uint8_t* rgb2, const double* rel4x4, const double K[4],
                             double factor, int B, int k, int H, int W, double* sums,
-                            uint32_t* counts, void* stream);
+                            uint32_t* counts, void* workspace, size_t workspace_bytes,
+                            void* stream);
 
 /* Same arithmetic as slamhip_pair_loss_fused, per-pixel results written out
  * (each output may be NULL): warped_rgb float32 [B,k,H,W,3], warped_depth

@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libslamhip.so")
+LIB_PATH = os.environ.get("SLAMHIP_LIB") or os.path.join(_HERE, "_lib", "libslamhip.so")
 
 NSUMS = 4
 NCOUNTS = 4
@@ -36,8 +36,10 @@ SIGNATURES = {
                            _c_void_p], _c_int),
     "slamhip_overlap_count": ([_c_void_p, ctypes.c_longlong, _c_double, _c_double, _c_void_p, _c_void_p,
                                _c_void_p], _c_int),
+    "slamhip_pair_loss_workspace_bytes": ([_c_int, _c_int], ctypes.c_size_t),
     "slamhip_pair_loss_fused": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
-                                 _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p], _c_int),
+                                 _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
+                                 ctypes.c_size_t, _c_void_p], _c_int),
     "slamhip_warp_materialize": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                   _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p], _c_int),

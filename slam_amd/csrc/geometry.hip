@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <climits>
+#include <cmath>
 #include <cstdint>
 
 #include "common.h"
@@ -301,56 +302,277 @@ warp_materialize_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __re
 // ---------------------------------------------------------------------------
 // fused frame-pair kernel
 // ---------------------------------------------------------------------------
-// One 256-thread workgroup owns a TILE_W x TILE_H block of anchor pixels; a
-// thread owns PX consecutive pixels of one row (one 16-byte depth load, three
-// 8-byte colour loads).  Per neighbour frame:
-//   A  project the PX pixels (float64), keep (iu, iv, fu, fv, d, flags);
-//   B  workgroup bounding box of the bilinear taps;
-//   C  stage that window of the neighbour frame (colour + depth) into LDS as
-//      8-byte cells {R|G<<8|B<<16, float(depth)} with 16-byte global loads;
+// One 256-thread workgroup owns a TILE_W x TILE_H tile of anchor pixels.  Wave w
+// owns rows 4w..4w+3 of the tile and walks them in eight steps of 64 consecutive
+// pixels, so that at every step the 64 lanes of a wave read 64 adjacent anchor
+// pixels (coalesced) and gather from adjacent LDS cells (no bank conflicts for
+// the smooth flow of small camera motions).  Per neighbour frame:
+//   A  project the eight pixels (float64), keep (tap address, fu, fv, d, flags);
+//   B  workgroup bounding box of the bilinear taps (DPP min/max, then LDS);
+//   C  stage that window of the neighbour frame into LDS as 8-byte cells
+//      {R|G<<8|B<<16, float(depth)} with 16-byte / 8-byte global loads;
 //   D  gather the four taps of every pixel from LDS, blend, accumulate;
 //   a window wider than WIN_PITCH or taller than WIN_ROWS (large parallax)
 //   falls back to gathering straight from global memory for that tile.
-// Sums are reduced by wave shuffles, then across the four waves through LDS,
-// then one float64 / uint32 atomic per quantity per workgroup.
-constexpr int PX = 8;
+// Reduction: counts by ballot+popcount, sums by DPP row reductions, the four
+// waves through LDS, then one float64 / uint32 atomic per quantity per
+// workgroup into the accumulators of the caller's workspace.  The workgroup
+// that draws the last ticket of an (image, neighbour) pair moves the totals to
+// the outputs with atomic exchanges, which also leaves the workspace zeroed for
+// the next call: no memset and no second kernel on the stream.
 constexpr int TILE_W = 128;
 constexpr int TILE_H = 16;
-constexpr int TPB = (TILE_W / PX) * TILE_H;   // 256
-constexpr int WIN_PITCH = 160;                // LDS window row pitch in cells (multiple of PX)
-constexpr int WIN_ROWS = 30;
-static_assert(TPB == 256, "tile must map to 256 threads");
+constexpr int TPB = 256;
+#ifndef SLAMHIP_HALVES
+#define SLAMHIP_HALVES 1
+#endif
+constexpr int HALVES = SLAMHIP_HALVES;           // a tile may be walked as two 128 x 8 halves
+constexpr int STEPS = (TILE_W * TILE_H) / TPB / HALVES;  // pixels per thread and half
+constexpr int CHUNK = 8;                        // staging granule in pixels (16 B of depth)
+#ifndef SLAMHIP_WIN_PITCH
+#define SLAMHIP_WIN_PITCH 160
+#endif
+#ifndef SLAMHIP_WIN_ROWS
+#define SLAMHIP_WIN_ROWS 30
+#endif
+#ifndef SLAMHIP_FUSED_WAVES
+#define SLAMHIP_FUSED_WAVES 3   // minimum waves per SIMD the register allocation must allow
+#endif
+constexpr int WIN_PITCH = SLAMHIP_WIN_PITCH;    // LDS window row pitch in cells (multiple of CHUNK)
+constexpr int WIN_ROWS = SLAMHIP_WIN_ROWS;
+static_assert(STEPS * HALVES == 8 && TILE_W == 128 && TILE_H == 16, "pixel walk below: 2 x 64 columns, STEPS/2 rows per wave and half");
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// workspace record of one (image, neighbour) pair: 64 bytes
+struct PairAcc {
+  double sums[SLAMHIP_NSUMS];
+  unsigned int counts[SLAMHIP_NCOUNTS];
+  unsigned int ticket;
+  unsigned int pad[3];
+};
+static_assert(sizeof(PairAcc) == 64, "PairAcc must stay 64 bytes");
+
+// DPP row/wave reductions: the result is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// `old` (what masked-out rows receive) is the identity of the operation, which
+// lets the compiler fold each step into one DPP-modified ALU instruction.
+__device__ __forceinline__ float wave_sum63(float v) {
+  v += dpp_f<0xB1, 0xF>(0.0f, v);         // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(0.0f, v);         // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(0.0f, v);        // row_half_mirror
+  v += dpp_f<0x140, 0xF>(0.0f, v);        // row_mirror
+  v += dpp_f<0x142, 0xA>(0.0f, v);        // row_bcast15 into rows 1,3
+  v += dpp_f<0x143, 0xC>(0.0f, v);        // row_bcast31 into rows 2,3
   return v;
 }
-__device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+__device__ __forceinline__ int wave_min63(int v) {
+  v = min(v, dpp_i<0xB1, 0xF>(INT_MAX, v));
+  v = min(v, dpp_i<0x4E, 0xF>(INT_MAX, v));
+  v = min(v, dpp_i<0x141, 0xF>(INT_MAX, v));
+  v = min(v, dpp_i<0x140, 0xF>(INT_MAX, v));
+  v = min(v, dpp_i<0x142, 0xA>(INT_MAX, v));
+  v = min(v, dpp_i<0x143, 0xC>(INT_MAX, v));
   return v;
 }
-__device__ __forceinline__ int wave_max(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+__device__ __forceinline__ int wave_max63(int v) {
+  v = max(v, dpp_i<0xB1, 0xF>(INT_MIN, v));
+  v = max(v, dpp_i<0x4E, 0xF>(INT_MIN, v));
+  v = max(v, dpp_i<0x141, 0xF>(INT_MIN, v));
+  v = max(v, dpp_i<0x140, 0xF>(INT_MIN, v));
+  v = max(v, dpp_i<0x142, 0xA>(INT_MIN, v));
+  v = max(v, dpp_i<0x143, 0xC>(INT_MIN, v));
   return v;
 }
 
-template <bool VEC>
-__global__ void __launch_bounds__(TPB)
+// Exact float64 division with the divisor-only work hoisted.  hipcc's IEEE a/b is
+//   s = div_scale(b); n = div_scale(a); r = rcp(s); two Newton steps on r;
+//   q = n*r; e = fma(-s, q, n); q = div_fmas(e, r, q); div_fixup(q, b, a)
+// and both div_scale and div_fmas/div_fixup are identities when a and b are
+// normal with exponents in [-300, 300] (no operand or quotient near the
+// denormal or overflow range).  refined_rcp() + div_by() are the remaining
+// instructions, so inside that band the quotient is bit-identical to a/b; the
+// callers check the band and use plain a/b outside it.
+__device__ __forceinline__ double refined_rcp(double b) {
+  double r = __builtin_amdgcn_rcp(b);
+  double e = fma(-b, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-b, r, 1.0);
+  r = fma(r, e, r);
+  return r;
+}
+__device__ __forceinline__ double div_by(double a, double b, double r) {
+  const double q = a * r;
+  const double e = fma(-b, q, a);
+  return fma(e, r, q);
+}
+__device__ __forceinline__ bool in_band(double v) {  // 2^-300 <= |v| < 2^301
+  const unsigned int hi = (unsigned int)__double2hiint(v) & 0x7fffffffu;
+  return (hi - (723u << 20)) < (601u << 20);
+}
+
+// LDS cell of one neighbour-frame pixel (8 bytes):
+//   x = half(R) | half(G) << 16,  y = half(B) | raw_depth << 16
+// 0..255 are exact in binary16, so colour differences are exact packed-half
+// subtractions and each interpolation step is one mixed-precision fma.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ half2_t as_half2(unsigned int v) { return __builtin_bit_cast(half2_t, v); }
+__device__ __forceinline__ unsigned int half_bits(unsigned int byte_value) {
+  return (unsigned int)__builtin_bit_cast(unsigned short, (_Float16)(unsigned short)byte_value);
+}
+__device__ __forceinline__ uint2 make_cell(unsigned int r, unsigned int g, unsigned int b, unsigned int depth) {
+  uint2 c;
+  c.x = half_bits(r) | (half_bits(g) << 16);
+  c.y = half_bits(b) | (depth << 16);
+  return c;
+}
+__device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b) {
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b) {
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+// packed (y << 16 | x) min / max over the wave, valid in lane 63
+__device__ __forceinline__ unsigned int wave_pk_min63(unsigned int v) {
+  v = pk_min_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x141, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x140, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x142, 0xA>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x143, 0xC>(-1, (int)v));
+  return v;
+}
+__device__ __forceinline__ unsigned int wave_pk_max63(unsigned int v) {
+  v = pk_max_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x141, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x140, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x142, 0xA>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x143, 0xC>(0, (int)v));
+  return v;
+}
+
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+struct Acc {   // per-thread partial sums of one neighbour frame; the two lanes of each
+  float2_t ap, sp, ag, sg;  // pair belong to even / odd steps and are added at the end
+};
+
+struct Cells {  // the four taps of one pixel
+  uint2 a, b, c, e;
+};
+
+// Horizontal interpolation of one pixel: top / bottom rows of R, G, B and depth.
+// Colour differences are exact in binary16; each lerp is one mixed-precision fma.
+__device__ __forceinline__ void lerp_rows(const Cells& t, float fu, float top[4], float bot[4]) {
+  const half2_t aRG = as_half2(t.a.x), cRG = as_half2(t.c.x);
+  const half2_t dT = as_half2(t.b.x) - aRG, dB = as_half2(t.e.x) - cRG;
+  const _Float16 aB = as_half2(t.a.y).x, cB = as_half2(t.c.y).x;
+  const _Float16 dTb = as_half2(t.b.y).x - aB, dBb = as_half2(t.e.y).x - cB;
+  top[0] = __builtin_fmaf(fu, (float)dT.x, (float)aRG.x);
+  top[1] = __builtin_fmaf(fu, (float)dT.y, (float)aRG.y);
+  top[2] = __builtin_fmaf(fu, (float)dTb, (float)aB);
+  bot[0] = __builtin_fmaf(fu, (float)dB.x, (float)cRG.x);
+  bot[1] = __builtin_fmaf(fu, (float)dB.y, (float)cRG.y);
+  bot[2] = __builtin_fmaf(fu, (float)dBb, (float)cB);
+  const float da = (float)(t.a.y >> 16), db = (float)(t.b.y >> 16), dc = (float)(t.c.y >> 16), de = (float)(t.e.y >> 16);
+  top[3] = __builtin_fmaf(fu, db - da, da);
+  bot[3] = __builtin_fmaf(fu, de - dc, dc);
+}
+
+__device__ __forceinline__ bool taps_nonzero(const Cells& t) {  // all four raw depths != 0
+  return min(min(t.a.y, t.b.y), min(t.c.y, t.e.y)) >= 0x10000u;
+}
+
+// Two pixels at once: everything after the horizontal lerps is packed float32
+// (v_pk_add / v_pk_mul / v_pk_fma work on both pixels in one instruction).
+// ok0/ok1: warp_valid.  Non-valid pixels have fu = fv = 0 and taps at cell 0, so
+// their values are finite and a 0/1 factor removes them from the colour sums.
+// Interpolation order as in the oracle (top, bottom, then vertical) with fused
+// multiply-adds; the deviation from the unfused float32 oracle is a few 1e-7.
+template <bool UNIT>
+__device__ __forceinline__ unsigned int blend_accumulate2(Acc& acc, const Cells& t0, const Cells& t1, float fu0,
+                                                          float fu1, float fv0, float fv1, bool ok0, bool ok1,
+                                                          float factor_f, const unsigned int rgb0[3],
+                                                          const unsigned int rgb1[3], double d0, double d1) {
+  float top0[4], bot0[4], top1[4], bot1[4];
+  lerp_rows(t0, fu0, top0, bot0);
+  lerp_rows(t1, fu1, top1, bot1);
+  const float2_t fv = {fv0, fv1};
+  const float2_t okf = {ok0 ? 1.0f : 0.0f, ok1 ? 1.0f : 0.0f};
+  float2_t w[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float2_t top = {top0[c], top1[c]}, bot = {bot0[c], bot1[c]};
+    w[c] = __builtin_elementwise_fma(fv, bot - top, top);
+  }
+  const float2_t rr = w[0] - float2_t{(float)rgb0[0], (float)rgb1[0]};
+  const float2_t rg = w[1] - float2_t{(float)rgb0[1], (float)rgb1[1]};
+  const float2_t rb = w[2] - float2_t{(float)rgb0[2], (float)rgb1[2]};
+  const float2_t ap = {(fabsf(rr.x) + fabsf(rg.x)) + fabsf(rb.x), (fabsf(rr.y) + fabsf(rg.y)) + fabsf(rb.y)};
+  const float2_t sp = __builtin_elementwise_fma(rb, rb, __builtin_elementwise_fma(rg, rg, rr * rr));
+  acc.ap = __builtin_elementwise_fma(okf, ap, acc.ap);
+  acc.sp = __builtin_elementwise_fma(okf, sp, acc.sp);
+  float2_t wd = w[3];
+  if (!UNIT) wd = wd / float2_t{factor_f, factor_f};
+  const bool geo0 = ok0 && taps_nonzero(t0), geo1 = ok1 && taps_nonzero(t1);
+  // depth residual in float64: d may be NaN/inf for a pixel that is not geo
+  const float g0 = geo0 ? (float)((double)wd.x - d0) : 0.0f;
+  const float g1 = geo1 ? (float)((double)wd.y - d1) : 0.0f;
+  const float2_t g = {g0, g1};
+  acc.ag += float2_t{fabsf(g0), fabsf(g1)};
+  acc.sg = __builtin_elementwise_fma(g, g, acc.sg);
+  return (geo0 ? 1u : 0u) | (geo1 ? 2u : 0u);
+}
+
+// Single-pixel form of blend_accumulate2 for the rare tiles that gather straight
+// from global memory; kept small so that it does not set the kernel's register count.
+template <bool UNIT>
+__device__ __forceinline__ bool blend_accumulate1(Acc& acc, const Cells& t, float fu, float fv, bool ok, float factor_f,
+                                                  const unsigned int rgb[3], double d) {
+  float top[4], bot[4], w[4];
+  lerp_rows(t, fu, top, bot);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) w[c] = __builtin_fmaf(fv, bot[c] - top[c], top[c]);
+  const float rr = w[0] - (float)rgb[0], rg = w[1] - (float)rgb[1], rb = w[2] - (float)rgb[2];
+  const float okf = ok ? 1.0f : 0.0f;
+  acc.ap.x = __builtin_fmaf(okf, (fabsf(rr) + fabsf(rg)) + fabsf(rb), acc.ap.x);
+  acc.sp.x = __builtin_fmaf(okf, __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, rr * rr)), acc.sp.x);
+  const float wd = UNIT ? w[3] : w[3] / factor_f;
+  const bool geo = ok && taps_nonzero(t);
+  const float g = geo ? (float)((double)wd - d) : 0.0f;
+  acc.ag.x += fabsf(g);
+  acc.sg.x = __builtin_fmaf(g, g, acc.sg.x);
+  return geo;
+}
+
+__device__ __forceinline__ uint2 global_cell(const uint16_t* __restrict__ d2, const uint8_t* __restrict__ c2, int W,
+                                             int x, int y) {
+  const int o = y * W + x;
+  return make_cell(c2[3 * o], c2[3 * o + 1], c2[3 * o + 2], d2[o]);
+}
+
+template <bool FAST, bool UNIT>
+__global__ void __launch_bounds__(TPB, SLAMHIP_FUSED_WAVES)
 pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
                        const uint16_t* __restrict__ depth2, const uint8_t* __restrict__ rgb2,
                        const double* __restrict__ rel, Cam cam, int B, int k, int H, int W,
-                       int tiles_x, int tiles_y, double* __restrict__ sums,
-                       unsigned int* __restrict__ counts) {
+                       int tiles_x, int tiles_y, int stage_vec, PairAcc* __restrict__ ws,
+                       double* __restrict__ sums, unsigned int* __restrict__ counts) {
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
-  __shared__ int s_box[4][4];
+  __shared__ unsigned int s_box[4][2];
   __shared__ float s_sum[4][4];
   __shared__ unsigned int s_cnt[4][4];
 
   // blocks that share (blockIdx % 8) run on one XCD and share its L2: give each
-  // such group whole images so a tile's halo rows/columns hit in L2.
+  // such group whole images so that a tile's halo rows/columns hit in L2.
   const int tiles = tiles_x * tiles_y;
   const int group = blockIdx.x & 7;
   const int slot = blockIdx.x >> 3;
@@ -361,186 +583,265 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int row = ty * TILE_H + tid / (TILE_W / PX);
-  const int col0 = tx * TILE_W + (tid % (TILE_W / PX)) * PX;
   const long long HW = (long long)H * W;
-  const bool row_ok = row < H;
-
-  // ---- anchor pixels: raw depth and colour of PX pixels ----
-  uint32_t draw[PX];
-  uint32_t crgb[PX];  // R | G<<8 | B<<16
-#pragma unroll
-  for (int i = 0; i < PX; ++i) { draw[i] = 0; crgb[i] = 0; }
-  if (row_ok) {
-    const long long o = (long long)b * HW + (long long)row * W + col0;
-    if (VEC && col0 + PX <= W) {
-      const uint4 dv = *reinterpret_cast<const uint4*>(depth1 + o);
-      const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
-#pragma unroll
-      for (int i = 0; i < PX; ++i) draw[i] = (dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu;
-      const uint2* cp = reinterpret_cast<const uint2*>(rgb1 + 3 * o);
-      const uint2 c0 = cp[0], c1 = cp[1], c2 = cp[2];
-      const uint32_t cw[6] = {c0.x, c0.y, c1.x, c1.y, c2.x, c2.y};
-#pragma unroll
-      for (int i = 0; i < PX; ++i) {
-        const int bo = 3 * i;  // byte offset of pixel i in the 24-byte group
-        const uint64_t two = (uint64_t)cw[bo >> 2] | ((uint64_t)cw[min((bo >> 2) + 1, 5)] << 32);
-        crgb[i] = (uint32_t)(two >> ((bo & 3) * 8)) & 0xffffffu;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < PX; ++i)
-        if (col0 + i < W) {
-          draw[i] = depth1[o + i];
-          const uint8_t* c = rgb1 + 3 * (o + i);
-          crgb[i] = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16);
-        }
-    }
-  }
+  const int colA = tx * TILE_W + lane;           // column at even steps; odd steps add 64
+  // wave-uniform plane bases + 32-bit per-lane offsets (clamped into the image)
+  const uint16_t* d1b = depth1 + (long long)b * HW;
+  const uint8_t* c1p = rgb1 + 3 * (long long)b * HW;
+  const int acol[2] = {min(colA, W - 1), min(colA + 64, W - 1)};
 
   const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
   const float factor_f = (float)cam.factor;
+  // divisor-only parts of the three constant divisions (UNIT: factor == 1, z is the raw depth)
+  const double r_fx = FAST ? refined_rcp(cam.fx) : 0.0;
+  const double r_fy = FAST ? refined_rcp(cam.fy) : 0.0;
+  const double r_fac = (FAST && !UNIT) ? refined_rcp(cam.factor) : 0.0;
+  const double ucx0 = (double)colA - cam.cx, ucx1 = (double)(colA + 64) - cam.cx;
 
   for (int j = 0; j < k; ++j) {
     const long long bj = (long long)b * k + j;
     const Pose p = load_pose(rel + 16 * bj);
     const uint16_t* d2 = depth2 + bj * HW;
     const uint8_t* c2 = rgb2 + 3 * bj * HW;
+    Acc acc = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_geo = 0;
+
+    // The tile is walked as two halves of eight rows, each with its own tap
+    // window: half the per-thread state of a one-shot walk (registers decide
+    // how many waves a SIMD holds, and that decides how well loads are hidden).
+#pragma unroll 1
+    for (int half = 0; half < HALVES; ++half) {
+    // step i of a thread = row (i>>1) of its wave's two rows, column (i&1)*64 + lane
+    const int row0 = ty * TILE_H + half * (TILE_H / HALVES) + wave * (STEPS / 2);
+    unsigned int live = 0;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const int r = row0 + (i >> 1), c = colA + (i & 1) * 64;
+      live |= ((r < H) && (c < W)) ? (1u << i) : 0u;
+    }
 
     // ---- A: project ----
-    int iu[PX], iv[PX];
-    float fu[PX], fv[PX];
-    double dd[PX];
-    unsigned int flags = 0;  // bit i: warp_valid of pixel i
-    unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_geo = 0;
-    int bx0 = INT_MAX, bx1 = INT_MIN, by0 = INT_MAX, by1 = INT_MIN;
+    unsigned int tap[STEPS];   // (iv << 16) | iu of the top-left tap; 0 when not warp_valid
+    float fu[STEPS], fv[STEPS];
+    double dd[STEPS];
+    unsigned int m_warp = 0;   // bit i: warp_valid of step i
+    unsigned int pmin = 0xffffffffu, pmax = 0u;   // packed (y << 16 | x) bounding box of the taps
+    unsigned int draw[STEPS];
 #pragma unroll
-    for (int i = 0; i < PX; ++i) {
+    for (int i = 0; i < STEPS; ++i) {
+      const int o = min(row0 + (i >> 1), H - 1) * W + acol[i & 1];
+      draw[i] = ((live >> i) & 1u) ? (unsigned int)d1b[o] : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      const double ucx = (i & 1) ? ucx1 : ucx0;
+      const double vcy = (double)(row0 + (i >> 1)) - cam.cy;
       double x, y, z, x2, y2, z2, u, v;
-      backproject_px(cam, col0 + i, row, draw[i], x, y, z);
+      bool valid0;
+      if (FAST) {
+        // test_import.py:153-155 with the constant divisors' reciprocals hoisted
+        z = UNIT ? (double)draw[i] : div_by((double)draw[i], cam.factor, r_fac);
+        x = div_by(ucx * z, cam.fx, r_fx);
+        y = div_by(vcy * z, cam.fy, r_fy);
+        // no product above can underflow (the host checked the constants), so
+        // "x, y, z all non-zero" is "raw depth, u-cx and v-cy all non-zero"
+        valid0 = (draw[i] != 0u) && (ucx != 0.0) && (vcy != 0.0);
+      } else {
+        z = UNIT ? (double)draw[i] : (double)draw[i] / cam.factor;
+        x = (ucx * z) / cam.fx;
+        y = (vcy * z) / cam.fy;
+        valid0 = (x != 0.0) && (y != 0.0) && (z != 0.0) && ((live >> i) & 1u);
+      }
       transform_px(p, x, y, z, x2, y2, z2);
-      project_px(cam, x2, y2, z2, u, v);
-      const bool live = row_ok && (col0 + i < W);
-      const bool valid0 = live && (x != 0.0 && y != 0.0 && z != 0.0);
+      const double nu = x2 * cam.fx, nv = y2 * cam.fy;
+      if (FAST) {
+        // Only the divisor's range matters: with z2 normal and mid-range, a zero,
+        // tiny, huge or non-finite numerator gives a quotient that is either exact
+        // or (tiny) absorbed by "+ cx" / (huge, NaN) outside every window either
+        // way, because the host admitted only |cx|, |cy| in [2^-32, 2^32].
+        const bool band = in_band(z2);
+        const double r_z = refined_rcp(z2);
+        u = div_by(nu, z2, r_z) + cam.cx;
+        v = div_by(nv, z2, r_z) + cam.cy;
+        if (valid0 && !band) {   // zero / huge / tiny / non-finite operands: plain IEEE division
+          u = nu / z2 + cam.cx;
+          v = nv / z2 + cam.cy;
+        }
+      } else {
+        u = nu / z2 + cam.cx;
+        v = nv / z2 + cam.cy;
+      }
       const bool inb = valid0 && in_window(u, v, dW, dH);
       const bool wv = valid0 && in_window(u, v, dW1, dH1) && (z2 > 0.0);
-      n_valid0 += valid0; n_inb += inb; n_warp += wv;
-      const double fl_u = floor(u), fl_v = floor(v);
-      iu[i] = wv ? (int)fl_u : 0;
-      iv[i] = wv ? (int)fl_v : 0;
-      fu[i] = (float)(u - fl_u);
-      fv[i] = (float)(v - fl_v);
+      n_valid0 += (unsigned int)__popcll(__ballot(valid0));
+      n_inb += (unsigned int)__popcll(__ballot(inb));
+      n_warp += (unsigned int)__popcll(__ballot(wv));
+      // u, v >= 0 when warp_valid: truncation is floor and fract() is u - floor(u)
+      const unsigned int t = ((unsigned int)(int)v << 16) | (unsigned int)(int)u;
+      // weights of pixels that do not warp are zeroed: their (u, v) may be NaN/inf
+      fu[i] = wv ? (float)__builtin_amdgcn_fract(u) : 0.0f;
+      fv[i] = wv ? (float)__builtin_amdgcn_fract(v) : 0.0f;
       dd[i] = z2;
-      if (wv) {
-        flags |= 1u << i;
-        bx0 = min(bx0, iu[i]); bx1 = max(bx1, iu[i]);
-        by0 = min(by0, iv[i]); by1 = max(by1, iv[i]);
-      }
+      tap[i] = wv ? t : 0u;
+      m_warp |= wv ? (1u << i) : 0u;
+      pmin = pk_min_u16(pmin, wv ? t : 0xffffffffu);
+      pmax = pk_max_u16(pmax, tap[i]);
+      // finish this pixel here: without the pin the optimiser sinks the tail of
+      // all eight pixels below the loop and keeps their float64 (u, v) alive
+      asm volatile("" : "+v"(tap[i]), "+v"(fu[i]), "+v"(fv[i]), "+v"(dd[i]), "+v"(pmin), "+v"(pmax));
     }
 
     // ---- B: workgroup bounding box of the taps ----
-    bx0 = wave_min(bx0); by0 = wave_min(by0); bx1 = wave_max(bx1); by1 = wave_max(by1);
-    if (lane == 0) { s_box[wave][0] = bx0; s_box[wave][1] = by0; s_box[wave][2] = bx1; s_box[wave][3] = by1; }
+    pmin = wave_pk_min63(pmin);
+    pmax = wave_pk_max63(pmax);
+    if (lane == 63) { s_box[wave][0] = pmin; s_box[wave][1] = pmax; }
     __syncthreads();
-    bx0 = min(min(s_box[0][0], s_box[1][0]), min(s_box[2][0], s_box[3][0]));
-    by0 = min(min(s_box[0][1], s_box[1][1]), min(s_box[2][1], s_box[3][1]));
-    bx1 = max(max(s_box[0][2], s_box[1][2]), max(s_box[2][2], s_box[3][2]));
-    by1 = max(max(s_box[0][3], s_box[1][3]), max(s_box[2][3], s_box[3][3]));
-    const bool any = bx1 >= bx0;                 // some pixel of the tile warps
-    const int wx0 = any ? (bx0 & ~(PX - 1)) : 0; // window origin, aligned to the staging chunk
+    pmin = pk_min_u16(pk_min_u16(s_box[0][0], s_box[1][0]), pk_min_u16(s_box[2][0], s_box[3][0]));
+    pmax = pk_max_u16(pk_max_u16(s_box[0][1], s_box[1][1]), pk_max_u16(s_box[2][1], s_box[3][1]));
+    const int bx0 = (int)(pmin & 0xffffu), by0 = (int)(pmin >> 16);
+    const int bx1 = (int)(pmax & 0xffffu), by1 = (int)(pmax >> 16);
+    const bool any = (pmin != 0xffffffffu);          // some pixel of the tile warps
+    const int wx0 = any ? (bx0 & ~(CHUNK - 1)) : 0;  // window origin, aligned to the staging granule
     const int wy0 = any ? by0 : 0;
-    const int ncols = any ? (bx1 + 2 - wx0) : 0; // taps reach iu+1 / iv+1
+    const int ncols = any ? (bx1 + 2 - wx0) : 0;     // taps reach iu+1 / iv+1
     const int nrows = any ? (by1 + 2 - wy0) : 0;
-    const bool use_lds = VEC && any && ncols <= WIN_PITCH && nrows <= WIN_ROWS;
+    const bool use_lds = stage_vec && any && ncols <= WIN_PITCH && nrows <= WIN_ROWS;
 
-    // ---- C: stage the window ----
+    // anchor colour of the first pixel pair: issued here so that the loads fly
+    // during the staging phase; later pairs are fetched one pair ahead of their use
+    auto load_rgb1 = [&](int i, unsigned int out[3]) {
+      const int o = 3 * (min(row0 + (i >> 1), H - 1) * W + acol[i & 1]);
+      out[0] = c1p[o];
+      out[1] = c1p[o + 1];
+      out[2] = c1p[o + 2];
+    };
+    unsigned int nxt0[3], nxt1[3];
+    load_rgb1(0, nxt0);
+    load_rgb1(1, nxt1);
+
+    unsigned int m_geo = 0;
+#ifdef SLAMHIP_ABL_NO_GATHER
+    if (false) {
+#else
     if (use_lds) {
-      const int chunks_x = (ncols + PX - 1) / PX;
+#endif
+      // ---- C: stage the window ----
+      const int chunks_x = (ncols + CHUNK - 1) / CHUNK;
       const int nchunks = chunks_x * nrows;
+#ifdef SLAMHIP_ABL_NO_STAGE
+      if (false)
+#endif
+#pragma unroll 1
       for (int c = tid; c < nchunks; c += TPB) {
         const int cr = c / chunks_x, cc = c - cr * chunks_x;
         const int sy = min(wy0 + cr, H - 1);        // clamp-to-edge rows
-        const int sx = wx0 + cc * PX;
-        uint2* dst = win + cr * WIN_PITCH + cc * PX;
-        if (sx + PX <= W) {
-          const long long o = (long long)sy * W + sx;
+        const int sx = wx0 + cc * CHUNK;
+        uint2* dst = win + cr * WIN_PITCH + cc * CHUNK;
+        if (sx + CHUNK <= W) {
+          const int o = sy * W + sx;
           const uint4 dv = *reinterpret_cast<const uint4*>(d2 + o);
           const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
           const uint2 q0 = cp[0], q1 = cp[1], q2 = cp[2];
           const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
           const uint32_t cw[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
 #pragma unroll
-          for (int i = 0; i < PX; ++i) {
-            const int bo = 3 * i;
-            const uint64_t two = (uint64_t)cw[bo >> 2] | ((uint64_t)cw[min((bo >> 2) + 1, 5)] << 32);
-            uint2 cell;
-            cell.x = (uint32_t)(two >> ((bo & 3) * 8)) & 0xffffffu;
-            cell.y = __float_as_uint((float)((dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu));
-            dst[i] = cell;
+          for (int i = 0; i < CHUNK; ++i) {
+            const int br = 3 * i, bg = 3 * i + 1, bb = 3 * i + 2;   // byte positions in the 24-byte group
+            dst[i] = make_cell((cw[br >> 2] >> ((br & 3) * 8)) & 0xffu, (cw[bg >> 2] >> ((bg & 3) * 8)) & 0xffu,
+                               (cw[bb >> 2] >> ((bb & 3) * 8)) & 0xffu, (dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
           }
         } else {
           // chunk past the right edge: replicate the last column (clamp-to-edge)
-          const long long o = (long long)sy * W + (W - 1);
-          uint2 cell;
-          cell.x = (uint32_t)c2[3 * o] | ((uint32_t)c2[3 * o + 1] << 8) | ((uint32_t)c2[3 * o + 2] << 16);
-          cell.y = __float_as_uint((float)d2[o]);
+          const uint2 cell = global_cell(d2, c2, W, W - 1, sy);
 #pragma unroll
-          for (int i = 0; i < PX; ++i) dst[i] = cell;
+          for (int i = 0; i < CHUNK; ++i) dst[i] = cell;
         }
       }
-    }
-    __syncthreads();
-
-    // ---- D: gather, blend, accumulate ----
-    float s_ap = 0.f, s_sp = 0.f, s_ag = 0.f, s_sg = 0.f;
+      __syncthreads();
+      // ---- D: gather from LDS, blend, accumulate (two pixels per step) ----
+      const int base = wy0 * WIN_PITCH + wx0;
 #pragma unroll
-    for (int i = 0; i < PX; ++i) {
-      if (flags & (1u << i)) {
-        Tap a, bb, c, e;
-        if (use_lds) {
-          const uint2* cell = win + (iv[i] - wy0) * WIN_PITCH + (iu[i] - wx0);
-          a = unpack_cell(cell[0]);
-          bb = unpack_cell(cell[1]);
-          c = unpack_cell(cell[WIN_PITCH]);
-          e = unpack_cell(cell[WIN_PITCH + 1]);
-        } else {
-          const int x1 = min(iu[i] + 1, W - 1), y1 = min(iv[i] + 1, H - 1);
-          a = global_tap(d2, c2, W, iu[i], iv[i]);
-          bb = global_tap(d2, c2, W, x1, iv[i]);
-          c = global_tap(d2, c2, W, iu[i], y1);
-          e = global_tap(d2, c2, W, x1, y1);
+      for (int i = 0; i < STEPS; i += 2) {
+        Cells t[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const bool ok = (m_warp >> (i + q)) & 1u;
+          const int off = ok ? ((int)(tap[i + q] >> 16) * WIN_PITCH + (int)(tap[i + q] & 0xffffu) - base) : 0;
+          const uint2* cell = win + off;
+          t[q].a = cell[0]; t[q].b = cell[1]; t[q].c = cell[WIN_PITCH]; t[q].e = cell[WIN_PITCH + 1];
         }
-        const WarpOut o = blend(a, bb, c, e, fu[i], fv[i], factor_f);
-        const float r0 = o.wr - (float)(crgb[i] & 0xffu);
-        const float r1 = o.wg - (float)((crgb[i] >> 8) & 0xffu);
-        const float r2 = o.wb - (float)((crgb[i] >> 16) & 0xffu);
-        s_ap += (fabsf(r0) + fabsf(r1)) + fabsf(r2);
-        s_sp += (r0 * r0 + r1 * r1) + r2 * r2;
-        if (o.geo) {
-          const float rg = (float)((double)o.wd - dd[i]);
-          s_ag += fabsf(rg);
-          s_sg += rg * rg;
-          n_geo += 1;
+        const unsigned int rgb0[3] = {nxt0[0], nxt0[1], nxt0[2]}, rgb1[3] = {nxt1[0], nxt1[1], nxt1[2]};
+        if (i + 2 < STEPS) {
+          load_rgb1(i + 2, nxt0);
+          load_rgb1(i + 3, nxt1);
         }
+        const unsigned int g = blend_accumulate2<UNIT>(acc, t[0], t[1], fu[i], fu[i + 1], fv[i], fv[i + 1],
+                                                       (m_warp >> i) & 1u, (m_warp >> (i + 1)) & 1u, factor_f, rgb0,
+                                                       rgb1, dd[i], dd[i + 1]);
+        m_geo |= g << i;
+        // one pair's taps in flight at a time, not all eight pixels'
+        asm volatile("" : "+v"(acc.ap), "+v"(acc.sp), "+v"(acc.ag), "+v"(acc.sg), "+v"(m_geo), "+v"(nxt0[0]),
+                     "+v"(nxt0[1]), "+v"(nxt0[2]), "+v"(nxt1[0]), "+v"(nxt1[1]), "+v"(nxt1[2]));
+      }
+#ifdef SLAMHIP_ABL_NO_GATHER
+    } else if (false) {
+#else
+    } else if (any) {
+#endif
+      // ---- D': gather straight from global memory, one pixel at a time ----
+#pragma unroll 1
+      for (int i = 0; i < STEPS; ++i) {
+        const int x0 = (int)(tap[i] & 0xffffu), y0 = (int)(tap[i] >> 16);
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        Cells t;
+        t.a = global_cell(d2, c2, W, x0, y0); t.b = global_cell(d2, c2, W, x1, y0);
+        t.c = global_cell(d2, c2, W, x0, y1); t.e = global_cell(d2, c2, W, x1, y1);
+        unsigned int rgb[3];
+        load_rgb1(i, rgb);
+        const bool geo = blend_accumulate1<UNIT>(acc, t, fu[i], fv[i], (m_warp >> i) & 1u, factor_f, rgb, dd[i]);
+        m_geo |= geo ? (1u << i) : 0u;
       }
     }
 
-    // ---- reduce: wave shuffles, then the four waves, then one atomic each ----
-    s_ap = wave_sum(s_ap); s_sp = wave_sum(s_sp); s_ag = wave_sum(s_ag); s_sg = wave_sum(s_sg);
-    const unsigned int c0 = (unsigned int)wave_sum((float)n_valid0), c1 = (unsigned int)wave_sum((float)n_inb);
-    const unsigned int c2n = (unsigned int)wave_sum((float)n_warp), c3 = (unsigned int)wave_sum((float)n_geo);
-    if (lane == 0) {
-      s_sum[wave][0] = s_ap; s_sum[wave][1] = s_sp; s_sum[wave][2] = s_ag; s_sum[wave][3] = s_sg;
-      s_cnt[wave][0] = c0; s_cnt[wave][1] = c1; s_cnt[wave][2] = c2n; s_cnt[wave][3] = c3;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) n_geo += (unsigned int)__popcll(__ballot((m_geo >> i) & 1u));
+    __syncthreads();   // every gather of this half is done before the window is restaged
+    }  // halves
+
+    // ---- reduce: DPP within the wave, LDS across the four waves, one atomic each ----
+    const float t0 = wave_sum63(acc.ap.x + acc.ap.y), t1 = wave_sum63(acc.sp.x + acc.sp.y);
+    const float t2 = wave_sum63(acc.ag.x + acc.ag.y), t3 = wave_sum63(acc.sg.x + acc.sg.y);
+    if (lane == 63) {
+      s_sum[wave][0] = t0; s_sum[wave][1] = t1; s_sum[wave][2] = t2; s_sum[wave][3] = t3;
+      s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; s_cnt[wave][2] = n_warp; s_cnt[wave][3] = n_geo;
     }
     __syncthreads();
-    if (tid < 4) {
-      const double t = ((double)s_sum[0][tid] + (double)s_sum[1][tid]) + ((double)s_sum[2][tid] + (double)s_sum[3][tid]);
-      atomicAdd(&sums[bj * SLAMHIP_NSUMS + tid], t);
-    } else if (tid < 8) {
-      const int q = tid - 4;
-      atomicAdd(&counts[bj * SLAMHIP_NCOUNTS + q], (s_cnt[0][q] + s_cnt[1][q]) + (s_cnt[2][q] + s_cnt[3][q]));
+    if (wave == 0) {
+      PairAcc* pa = ws + bj;
+      if (lane < 4) {
+        const double t = ((double)s_sum[0][lane] + (double)s_sum[1][lane]) + ((double)s_sum[2][lane] + (double)s_sum[3][lane]);
+        atomicAdd(&pa->sums[lane], t);
+      } else if (lane < 8) {
+        const int q = lane - 4;
+        atomicAdd(&pa->counts[q], (s_cnt[0][q] + s_cnt[1][q]) + (s_cnt[2][q] + s_cnt[3][q]));
+      }
+#ifdef SLAMHIP_ABL_NO_TICKET
+      continue;
+#endif
+      // every add of this workgroup has been performed before its ticket is drawn
+      __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+      unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(&pa->ticket, 1u);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t == (unsigned int)tiles - 1u) {
+        // last workgroup of this pair: totals out, accumulators back to zero
+        if (lane < 4) sums[bj * SLAMHIP_NSUMS + lane] = atomicExch(&pa->sums[lane], 0.0);
+        else if (lane < 8) counts[bj * SLAMHIP_NCOUNTS + (lane - 4)] = atomicExch(&pa->counts[lane - 4], 0u);
+        else if (lane == 8) atomicExch(&pa->ticket, 0u);
+      }
     }
+    // s_box / s_sum / win are rewritten by the next neighbour only after every
+    // thread has passed the barrier above and the one after the bounding box
   }
 }
 
@@ -622,31 +923,50 @@ int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double d
   return SLAMHIP_OK;
 }
 
+size_t slamhip_pair_loss_workspace_bytes(int B, int k) {
+  if (B <= 0 || k <= 0) return 0;
+  return sizeof(PairAcc) * (size_t)B * (size_t)k;
+}
+
 int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
                             const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
-                            int B, int k, int H, int W, double* sums, uint32_t* counts, void* stream) {
+                            int B, int k, int H, int W, double* sums, uint32_t* counts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
   SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
                   "pair_loss_fused: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
   if (B == 0) return SLAMHIP_OK;  // an empty batch has no buffers to check
-  SLAMHIP_REQUIRE(depth1 && rgb1 && depth2 && rgb2 && rel4x4 && K && sums && counts, SLAMHIP_E_ARG,
+  SLAMHIP_REQUIRE(depth1 && rgb1 && depth2 && rgb2 && rel4x4 && K && sums && counts && workspace, SLAMHIP_E_ARG,
                   "pair_loss_fused: null pointer");
+  SLAMHIP_REQUIRE(H <= 32767 && W <= 65535 && (long long)H * W <= 0x20000000LL, SLAMHIP_E_SIZE,
+                  "pair_loss_fused: image larger than 65535 x 32767 or 2^29 pixels");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_pair_loss_workspace_bytes(B, k), SLAMHIP_E_SIZE,
+                  "pair_loss_fused: workspace of %zu bytes, need %zu", workspace_bytes,
+                  slamhip_pair_loss_workspace_bytes(B, k));
+  SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4), SLAMHIP_E_ARG,
+                  "pair_loss_fused: misaligned workspace or output");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(sums, 0, sizeof(double) * SLAMHIP_NSUMS * (size_t)B * k, s));
-  SLAMHIP_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * SLAMHIP_NCOUNTS * (size_t)B * k, s));
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const long long groups = ((long long)B + 7) / 8;
   const long long nblocks = groups * 8 * tiles_x * tiles_y;
   SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "pair_loss_fused: grid too large");
   const Cam cam{K[0], K[1], K[2], K[3], factor};
-  // the 16-byte / 8-byte vector loads need W % 8 == 0 and 16-byte aligned planes
-  const bool vec = (W % PX == 0) && aligned_to(depth1, 16) && aligned_to(depth2, 16) &&
-                   aligned_to(rgb1, 8) && aligned_to(rgb2, 8);
-  if (vec)
-    hipLaunchKernelGGL(pair_loss_fused_kernel<true>, dim3((unsigned)nblocks), dim3(TPB), 0, s, depth1, rgb1,
-                       depth2, rgb2, rel4x4, cam, B, k, H, W, tiles_x, tiles_y, sums, counts);
-  else
-    hipLaunchKernelGGL(pair_loss_fused_kernel<false>, dim3((unsigned)nblocks), dim3(TPB), 0, s, depth1, rgb1,
-                       depth2, rgb2, rel4x4, cam, B, k, H, W, tiles_x, tiles_y, sums, counts);
+  // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
+  const int stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
+  // hoisted-reciprocal divisions are exact while nothing comes near the denormal
+  // or overflow range: constants in [2^-64, 2^64], principal point in [2^-32, 2^32]
+  auto mid = [](double v) { const double a = fabs(v); return a >= 0x1p-64 && a <= 0x1p64; };
+  auto pp = [](double v) { const double a = fabs(v); return a >= 0x1p-32 && a <= 0x1p32; };
+  const bool fast = mid(K[0]) && mid(K[1]) && mid(factor) && pp(K[2]) && pp(K[3]);
+  PairAcc* ws = (PairAcc*)workspace;
+  const bool unit = factor == 1.0;
+#define SLAMHIP_LAUNCH_FUSED(F, U)                                                                         \
+  hipLaunchKernelGGL((pair_loss_fused_kernel<F, U>), dim3((unsigned)nblocks), dim3(TPB), 0, s, depth1, rgb1, \
+                     depth2, rgb2, rel4x4, cam, B, k, H, W, tiles_x, tiles_y, stage_vec, ws, sums, counts)
+  if (fast && unit) SLAMHIP_LAUNCH_FUSED(true, true);
+  else if (fast) SLAMHIP_LAUNCH_FUSED(true, false);
+  else if (unit) SLAMHIP_LAUNCH_FUSED(false, true);
+  else SLAMHIP_LAUNCH_FUSED(false, false);
+#undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

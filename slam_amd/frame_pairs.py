@@ -120,6 +120,20 @@ def _pair_args(depth1, rgb1, depth2, rgb2, rel):
     return d1, c1, d2.contiguous(), c2.contiguous(), r, B, k, H, W
 
 
+_workspaces = {}
+
+
+def _workspace(device, stream, nbytes):
+    """Zero-filled scratch of the fused kernel, one per (device, stream); the
+    kernel hands it back zero-filled, so it is cleared only when (re)allocated."""
+    key = (device.index, stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros((max(nbytes, 1 << 16),), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
 def pair_loss(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR, out=None):
     """The fused kernel: returns (sums float64 [B,k,4], counts int32 [B,k,4]).
     sums = (sum|r_photo|, sum r_photo^2, sum|r_geo|, sum r_geo^2),
@@ -131,10 +145,12 @@ def pair_loss(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR, out=None):
     else:
         sums, counts = out
     lib = capi.load()
+    stream = capi.current_stream()
+    ws = _workspace(d1.device, stream, lib.slamhip_pair_loss_workspace_bytes(B, k))
     capi.check(lib.slamhip_pair_loss_fused(d1.data_ptr(), c1.data_ptr(), d2.data_ptr(), c2.data_ptr(),
                                            r.data_ptr(), capi.K4(K), float(factor), B, k, H, W,
-                                           sums.data_ptr(), counts.data_ptr(), capi.current_stream()),
-               "slamhip_pair_loss_fused")
+                                           sums.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                           stream), "slamhip_pair_loss_fused")
     return sums, counts
 
 
