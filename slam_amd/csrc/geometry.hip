@@ -333,10 +333,10 @@ constexpr int CHUNK = 8;                        // staging granule in pixels (16
 #define SLAMHIP_WIN_PITCH 160
 #endif
 #ifndef SLAMHIP_WIN_ROWS
-#define SLAMHIP_WIN_ROWS 30
+#define SLAMHIP_WIN_ROWS 24
 #endif
 #ifndef SLAMHIP_FUSED_WAVES
-#define SLAMHIP_FUSED_WAVES 3   // minimum waves per SIMD the register allocation must allow
+#define SLAMHIP_FUSED_WAVES 4   // minimum waves per SIMD the register allocation must allow
 #endif
 constexpr int WIN_PITCH = SLAMHIP_WIN_PITCH;    // LDS window row pitch in cells (multiple of CHUNK)
 constexpr int WIN_ROWS = SLAMHIP_WIN_ROWS;
@@ -559,6 +559,17 @@ __device__ __forceinline__ uint2 global_cell(const uint16_t* __restrict__ d2, co
   return make_cell(c2[3 * o], c2[3 * o + 1], c2[3 * o + 2], d2[o]);
 }
 
+// Projection of one anchor pixel in float32, for window prediction only.
+__device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u0, float v0, float z, float& u,
+                                            float& v, float& z2) {
+  const float x = (u0 - (float)c.cx) * z / (float)c.fx, y = (v0 - (float)c.cy) * z / (float)c.fy;
+  const float x2 = x * (float)p.r00 + y * (float)p.r10 + z * (float)p.r20 + (float)p.t0;
+  const float y2 = x * (float)p.r01 + y * (float)p.r11 + z * (float)p.r21 + (float)p.t1;
+  z2 = x * (float)p.r02 + y * (float)p.r12 + z * (float)p.r22 + (float)p.t2;
+  u = x2 * (float)c.fx / z2 + (float)c.cx;
+  v = y2 * (float)c.fy / z2 + (float)c.cy;
+}
+
 template <bool FAST, bool UNIT>
 __global__ void __launch_bounds__(TPB, SLAMHIP_FUSED_WAVES)
 pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
@@ -567,7 +578,7 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
                        int tiles_x, int tiles_y, int stage_vec, PairAcc* __restrict__ ws,
                        double* __restrict__ sums, unsigned int* __restrict__ counts) {
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
-  __shared__ unsigned int s_box[4][2];
+  __shared__ unsigned int s_rng[4][2];
   __shared__ float s_sum[4][4];
   __shared__ unsigned int s_cnt[4][4];
 
@@ -584,11 +595,20 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const long long HW = (long long)H * W;
-  const int colA = tx * TILE_W + lane;           // column at even steps; odd steps add 64
+  // step i of a thread = row (i>>1) of its wave's four rows, column (i&1)*64 + lane
+  const int row0 = ty * TILE_H + wave * (STEPS / 2);
+  const int colA = tx * TILE_W + lane;
+  unsigned int live = 0;
+#pragma unroll
+  for (int i = 0; i < STEPS; ++i) {
+    const int r = row0 + (i >> 1), c = colA + (i & 1) * 64;
+    live |= ((r < H) && (c < W)) ? (1u << i) : 0u;
+  }
   // wave-uniform plane bases + 32-bit per-lane offsets (clamped into the image)
   const uint16_t* d1b = depth1 + (long long)b * HW;
   const uint8_t* c1p = rgb1 + 3 * (long long)b * HW;
   const int acol[2] = {min(colA, W - 1), min(colA + 64, W - 1)};
+  auto anchor_offset = [&](int i) { return min(row0 + (i >> 1), H - 1) * W + acol[i & 1]; };
 
   const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
   const float factor_f = (float)cam.factor;
@@ -598,56 +618,128 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
   const double r_fac = (FAST && !UNIT) ? refined_rcp(cam.factor) : 0.0;
   const double ucx0 = (double)colA - cam.cx, ucx1 = (double)(colA + 64) - cam.cx;
 
+  // anchor depth of the eight steps and the tile's range of non-zero depth
+  unsigned int zmn = 0xffffu, zmx = 0u;
+  {
+    unsigned int draw[STEPS];
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) draw[i] = ((live >> i) & 1u) ? (unsigned int)d1b[anchor_offset(i)] : 0u;
+#pragma unroll
+    for (int i = 0; i < STEPS; ++i) {
+      zmn = min(zmn, draw[i] ? draw[i] : 0xffffu);
+      zmx = max(zmx, draw[i]);
+    }
+  }
+  {
+    const unsigned int pk = wave_pk_min63(zmn | 0xffff0000u), px = wave_pk_max63(zmx);
+    if (lane == 63) { s_rng[wave][0] = pk; s_rng[wave][1] = px; }
+  }
+  __syncthreads();
+  zmn = min(min(s_rng[0][0], s_rng[1][0]), min(s_rng[2][0], s_rng[3][0])) & 0xffffu;
+  zmx = max(max(s_rng[0][1], s_rng[1][1]), max(s_rng[2][1], s_rng[3][1])) & 0xffffu;
+  const bool any_depth = zmx != 0u;
+
   for (int j = 0; j < k; ++j) {
     const long long bj = (long long)b * k + j;
     const Pose p = load_pose(rel + 16 * bj);
     const uint16_t* d2 = depth2 + bj * HW;
     const uint8_t* c2 = rgb2 + 3 * bj * HW;
+
+    // ---- predicted tap window: the tile's corners at the nearest and farthest depth ----
+    // For a fixed depth the tile maps to a convex quadrilateral, and a pixel moves
+    // along a segment as its depth varies, so the eight projected points bound
+    // every tap.  The window is only a cache: a tap outside it is gathered from
+    // global memory, so the prediction (float32, with a margin) affects speed only.
+    int wx0 = 0, wy0 = 0, ncols = 0, nrows = 0;
+    if (any_depth) {
+      const int cx_ = (lane & 1) ? min(tx * TILE_W + TILE_W - 1, W - 1) : tx * TILE_W;
+      const int cy_ = (lane & 2) ? min(ty * TILE_H + TILE_H - 1, H - 1) : ty * TILE_H;
+      const float zc = (float)((lane & 4) ? zmx : zmn) / factor_f;
+      float pu, pv, pz;
+      project_f32(cam, p, (float)cx_, (float)cy_, zc, pu, pv, pz);
+      const bool okp = (lane < 8) && (pz > 0.0f) && (fabsf(pu) < 1e6f) && (fabsf(pv) < 1e6f);   // NaN fails
+      const bool bad = __ballot((lane < 8) && !okp) != 0ull;
+      const int lo_u = okp ? max((int)floorf(pu) - 2, 0) : 0x7fff, lo_v = okp ? max((int)floorf(pv) - 2, 0) : 0x7fff;
+      const int hi_u = okp ? min((int)floorf(pu) + 3, W - 1) : 0, hi_v = okp ? min((int)floorf(pv) + 3, H - 1) : 0;
+      const unsigned int pmin = wave_pk_min63(((unsigned int)min(lo_v, 0x7fff) << 16) | (unsigned int)min(lo_u, 0xffff));
+      const unsigned int pmax = wave_pk_max63(((unsigned int)max(hi_v, 0) << 16) | (unsigned int)max(hi_u, 0));
+      const unsigned int bmin = (unsigned int)__builtin_amdgcn_readlane((int)pmin, 63);
+      const unsigned int bmax = (unsigned int)__builtin_amdgcn_readlane((int)pmax, 63);
+      const int bx0 = (int)(bmin & 0xffffu), by0 = (int)(bmin >> 16), bx1 = (int)(bmax & 0xffffu), by1 = (int)(bmax >> 16);
+      if (!bad && bx1 >= bx0 && by1 >= by0 && stage_vec) {
+        wx0 = bx0 & ~(CHUNK - 1);
+        wy0 = by0;
+        ncols = min(bx1 + 1 - wx0, WIN_PITCH);   // a larger box is cut: the rest goes the slow way
+        nrows = min(by1 + 1 - wy0, WIN_ROWS);
+        if (ncols < 2 || nrows < 2) ncols = nrows = 0;   // a tap needs two columns and two rows
+      }
+    }
+    // Pixels without taps in the window (not warp_valid, or missed) still read the
+    // window's first 2 x 2 cells with zero weights: keep those cells finite.
+    if (nrows == 0 && tid < 4) win[(tid >> 1) * WIN_PITCH + (tid & 1)] = make_uint2(0u, 0u);
+
+    // ---- stage the window: 8-byte cells {half R | half G, half B | raw depth} ----
+    const int chunks_x = (ncols + CHUNK - 1) / CHUNK;
+    const int nchunks = chunks_x * nrows;
+#ifdef SLAMHIP_ABL_NO_STAGE
+    if (false)
+#endif
+#pragma unroll 1
+    for (int c = tid; c < nchunks; c += TPB) {
+      const int cr = c / chunks_x, cc = c - cr * chunks_x;
+      const int sy = wy0 + cr;                    // <= H - 1 by construction
+      const int sx = wx0 + cc * CHUNK;            // < W, multiple of CHUNK, W % CHUNK == 0
+      uint2* dst = win + cr * WIN_PITCH + cc * CHUNK;
+      const int o = sy * W + sx;
+      const uint4 dv = *reinterpret_cast<const uint4*>(d2 + o);
+      const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
+      const uint2 q0 = cp[0], q1 = cp[1], q2 = cp[2];
+      const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+      const uint32_t cw[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) {
+        const int br = 3 * i, bg = 3 * i + 1, bb = 3 * i + 2;   // byte positions in the 24-byte group
+        dst[i] = make_cell((cw[br >> 2] >> ((br & 3) * 8)) & 0xffu, (cw[bg >> 2] >> ((bg & 3) * 8)) & 0xffu,
+                           (cw[bb >> 2] >> ((bb & 3) * 8)) & 0xffu, (dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
+      }
+    }
+    __syncthreads();
+
+    // ---- per pixel: project (float64), gather the four taps, blend, accumulate ----
     Acc acc = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
     unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_geo = 0;
-
-    // The tile is walked as two halves of eight rows, each with its own tap
-    // window: half the per-thread state of a one-shot walk (registers decide
-    // how many waves a SIMD holds, and that decides how well loads are hidden).
+    // a tap (du, dv) is in the window when du < lim_u and dv < lim_v (unsigned compares)
+    const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
+    // anchor depth and colour are (re)loaded one step ahead of their use; the
+    // loop is deliberately not unrolled: one pixel's live set, small code
+    unsigned int nxt[4];
+    {
+      const int o = anchor_offset(0);
+      nxt[0] = c1p[3 * o]; nxt[1] = c1p[3 * o + 1]; nxt[2] = c1p[3 * o + 2]; nxt[3] = d1b[o];
+    }
+#ifndef SLAMHIP_ABL_NO_GATHER
 #pragma unroll 1
-    for (int half = 0; half < HALVES; ++half) {
-    // step i of a thread = row (i>>1) of its wave's two rows, column (i&1)*64 + lane
-    const int row0 = ty * TILE_H + half * (TILE_H / HALVES) + wave * (STEPS / 2);
-    unsigned int live = 0;
-#pragma unroll
     for (int i = 0; i < STEPS; ++i) {
-      const int r = row0 + (i >> 1), c = colA + (i & 1) * 64;
-      live |= ((r < H) && (c < W)) ? (1u << i) : 0u;
-    }
-
-    // ---- A: project ----
-    unsigned int tap[STEPS];   // (iv << 16) | iu of the top-left tap; 0 when not warp_valid
-    float fu[STEPS], fv[STEPS];
-    double dd[STEPS];
-    unsigned int m_warp = 0;   // bit i: warp_valid of step i
-    unsigned int pmin = 0xffffffffu, pmax = 0u;   // packed (y << 16 | x) bounding box of the taps
-    unsigned int draw[STEPS];
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-      const int o = min(row0 + (i >> 1), H - 1) * W + acol[i & 1];
-      draw[i] = ((live >> i) & 1u) ? (unsigned int)d1b[o] : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
+      const unsigned int rgb[3] = {nxt[0], nxt[1], nxt[2]};
+      const unsigned int draw_i = ((live >> i) & 1u) ? nxt[3] : 0u;
+      {
+        const int o = anchor_offset(min(i + 1, STEPS - 1));
+        nxt[0] = c1p[3 * o]; nxt[1] = c1p[3 * o + 1]; nxt[2] = c1p[3 * o + 2]; nxt[3] = d1b[o];
+      }
       const double ucx = (i & 1) ? ucx1 : ucx0;
       const double vcy = (double)(row0 + (i >> 1)) - cam.cy;
       double x, y, z, x2, y2, z2, u, v;
       bool valid0;
       if (FAST) {
         // test_import.py:153-155 with the constant divisors' reciprocals hoisted
-        z = UNIT ? (double)draw[i] : div_by((double)draw[i], cam.factor, r_fac);
+        z = UNIT ? (double)draw_i : div_by((double)draw_i, cam.factor, r_fac);
         x = div_by(ucx * z, cam.fx, r_fx);
         y = div_by(vcy * z, cam.fy, r_fy);
         // no product above can underflow (the host checked the constants), so
         // "x, y, z all non-zero" is "raw depth, u-cx and v-cy all non-zero"
-        valid0 = (draw[i] != 0u) && (ucx != 0.0) && (vcy != 0.0);
+        valid0 = (draw_i != 0u) && (ucx != 0.0) && (vcy != 0.0);
       } else {
-        z = UNIT ? (double)draw[i] : (double)draw[i] / cam.factor;
+        z = UNIT ? (double)draw_i : (double)draw_i / cam.factor;
         x = (ucx * z) / cam.fx;
         y = (vcy * z) / cam.fy;
         valid0 = (x != 0.0) && (y != 0.0) && (z != 0.0) && ((live >> i) & 1u);
@@ -663,7 +755,7 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
         const double r_z = refined_rcp(z2);
         u = div_by(nu, z2, r_z) + cam.cx;
         v = div_by(nv, z2, r_z) + cam.cy;
-        if (valid0 && !band) {   // zero / huge / tiny / non-finite operands: plain IEEE division
+        if (valid0 && !band) {   // zero / huge / tiny / non-finite divisor: plain IEEE division
           u = nu / z2 + cam.cx;
           v = nv / z2 + cam.cy;
         }
@@ -676,137 +768,28 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
       n_valid0 += (unsigned int)__popcll(__ballot(valid0));
       n_inb += (unsigned int)__popcll(__ballot(inb));
       n_warp += (unsigned int)__popcll(__ballot(wv));
-      // u, v >= 0 when warp_valid: truncation is floor and fract() is u - floor(u)
-      const unsigned int t = ((unsigned int)(int)v << 16) | (unsigned int)(int)u;
-      // weights of pixels that do not warp are zeroed: their (u, v) may be NaN/inf
-      fu[i] = wv ? (float)__builtin_amdgcn_fract(u) : 0.0f;
-      fv[i] = wv ? (float)__builtin_amdgcn_fract(v) : 0.0f;
-      dd[i] = z2;
-      tap[i] = wv ? t : 0u;
-      m_warp |= wv ? (1u << i) : 0u;
-      pmin = pk_min_u16(pmin, wv ? t : 0xffffffffu);
-      pmax = pk_max_u16(pmax, tap[i]);
-      // finish this pixel here: without the pin the optimiser sinks the tail of
-      // all eight pixels below the loop and keeps their float64 (u, v) alive
-      asm volatile("" : "+v"(tap[i]), "+v"(fu[i]), "+v"(fv[i]), "+v"(dd[i]), "+v"(pmin), "+v"(pmax));
+      // u, v >= 0 when warp_valid: truncation is floor and fract() is u - floor(u);
+      // the weights of pixels that do not warp are zeroed (their u, v may be NaN/inf)
+      const int iu = wv ? (int)u : 0, iv = wv ? (int)v : 0;
+      const float fu = wv ? (float)__builtin_amdgcn_fract(u) : 0.0f;
+      const float fv = wv ? (float)__builtin_amdgcn_fract(v) : 0.0f;
+      const int du = iu - wx0, dv_ = iv - wy0;
+      const bool hit = wv && ((unsigned int)du < lim_u) && ((unsigned int)dv_ < lim_v);
+      const uint2* cell = win + (hit ? dv_ * WIN_PITCH + du : 0);
+      Cells t;
+      t.a = cell[0]; t.b = cell[1]; t.c = cell[WIN_PITCH]; t.e = cell[WIN_PITCH + 1];
+      const bool miss = wv && !hit;
+      if (__ballot(miss) != 0ull) {   // rare: taps outside the staged window
+        if (miss) {
+          const int x1 = min(iu + 1, W - 1), y1 = min(iv + 1, H - 1);
+          t.a = global_cell(d2, c2, W, iu, iv); t.b = global_cell(d2, c2, W, x1, iv);
+          t.c = global_cell(d2, c2, W, iu, y1); t.e = global_cell(d2, c2, W, x1, y1);
+        }
+      }
+      const bool geo = blend_accumulate1<UNIT>(acc, t, fu, fv, wv, factor_f, rgb, z2);
+      n_geo += (unsigned int)__popcll(__ballot(geo));
     }
-
-    // ---- B: workgroup bounding box of the taps ----
-    pmin = wave_pk_min63(pmin);
-    pmax = wave_pk_max63(pmax);
-    if (lane == 63) { s_box[wave][0] = pmin; s_box[wave][1] = pmax; }
-    __syncthreads();
-    pmin = pk_min_u16(pk_min_u16(s_box[0][0], s_box[1][0]), pk_min_u16(s_box[2][0], s_box[3][0]));
-    pmax = pk_max_u16(pk_max_u16(s_box[0][1], s_box[1][1]), pk_max_u16(s_box[2][1], s_box[3][1]));
-    const int bx0 = (int)(pmin & 0xffffu), by0 = (int)(pmin >> 16);
-    const int bx1 = (int)(pmax & 0xffffu), by1 = (int)(pmax >> 16);
-    const bool any = (pmin != 0xffffffffu);          // some pixel of the tile warps
-    const int wx0 = any ? (bx0 & ~(CHUNK - 1)) : 0;  // window origin, aligned to the staging granule
-    const int wy0 = any ? by0 : 0;
-    const int ncols = any ? (bx1 + 2 - wx0) : 0;     // taps reach iu+1 / iv+1
-    const int nrows = any ? (by1 + 2 - wy0) : 0;
-    const bool use_lds = stage_vec && any && ncols <= WIN_PITCH && nrows <= WIN_ROWS;
-
-    // anchor colour of the first pixel pair: issued here so that the loads fly
-    // during the staging phase; later pairs are fetched one pair ahead of their use
-    auto load_rgb1 = [&](int i, unsigned int out[3]) {
-      const int o = 3 * (min(row0 + (i >> 1), H - 1) * W + acol[i & 1]);
-      out[0] = c1p[o];
-      out[1] = c1p[o + 1];
-      out[2] = c1p[o + 2];
-    };
-    unsigned int nxt0[3], nxt1[3];
-    load_rgb1(0, nxt0);
-    load_rgb1(1, nxt1);
-
-    unsigned int m_geo = 0;
-#ifdef SLAMHIP_ABL_NO_GATHER
-    if (false) {
-#else
-    if (use_lds) {
 #endif
-      // ---- C: stage the window ----
-      const int chunks_x = (ncols + CHUNK - 1) / CHUNK;
-      const int nchunks = chunks_x * nrows;
-#ifdef SLAMHIP_ABL_NO_STAGE
-      if (false)
-#endif
-#pragma unroll 1
-      for (int c = tid; c < nchunks; c += TPB) {
-        const int cr = c / chunks_x, cc = c - cr * chunks_x;
-        const int sy = min(wy0 + cr, H - 1);        // clamp-to-edge rows
-        const int sx = wx0 + cc * CHUNK;
-        uint2* dst = win + cr * WIN_PITCH + cc * CHUNK;
-        if (sx + CHUNK <= W) {
-          const int o = sy * W + sx;
-          const uint4 dv = *reinterpret_cast<const uint4*>(d2 + o);
-          const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
-          const uint2 q0 = cp[0], q1 = cp[1], q2 = cp[2];
-          const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
-          const uint32_t cw[6] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y};
-#pragma unroll
-          for (int i = 0; i < CHUNK; ++i) {
-            const int br = 3 * i, bg = 3 * i + 1, bb = 3 * i + 2;   // byte positions in the 24-byte group
-            dst[i] = make_cell((cw[br >> 2] >> ((br & 3) * 8)) & 0xffu, (cw[bg >> 2] >> ((bg & 3) * 8)) & 0xffu,
-                               (cw[bb >> 2] >> ((bb & 3) * 8)) & 0xffu, (dw[i >> 1] >> ((i & 1) * 16)) & 0xffffu);
-          }
-        } else {
-          // chunk past the right edge: replicate the last column (clamp-to-edge)
-          const uint2 cell = global_cell(d2, c2, W, W - 1, sy);
-#pragma unroll
-          for (int i = 0; i < CHUNK; ++i) dst[i] = cell;
-        }
-      }
-      __syncthreads();
-      // ---- D: gather from LDS, blend, accumulate (two pixels per step) ----
-      const int base = wy0 * WIN_PITCH + wx0;
-#pragma unroll
-      for (int i = 0; i < STEPS; i += 2) {
-        Cells t[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          const bool ok = (m_warp >> (i + q)) & 1u;
-          const int off = ok ? ((int)(tap[i + q] >> 16) * WIN_PITCH + (int)(tap[i + q] & 0xffffu) - base) : 0;
-          const uint2* cell = win + off;
-          t[q].a = cell[0]; t[q].b = cell[1]; t[q].c = cell[WIN_PITCH]; t[q].e = cell[WIN_PITCH + 1];
-        }
-        const unsigned int rgb0[3] = {nxt0[0], nxt0[1], nxt0[2]}, rgb1[3] = {nxt1[0], nxt1[1], nxt1[2]};
-        if (i + 2 < STEPS) {
-          load_rgb1(i + 2, nxt0);
-          load_rgb1(i + 3, nxt1);
-        }
-        const unsigned int g = blend_accumulate2<UNIT>(acc, t[0], t[1], fu[i], fu[i + 1], fv[i], fv[i + 1],
-                                                       (m_warp >> i) & 1u, (m_warp >> (i + 1)) & 1u, factor_f, rgb0,
-                                                       rgb1, dd[i], dd[i + 1]);
-        m_geo |= g << i;
-        // one pair's taps in flight at a time, not all eight pixels'
-        asm volatile("" : "+v"(acc.ap), "+v"(acc.sp), "+v"(acc.ag), "+v"(acc.sg), "+v"(m_geo), "+v"(nxt0[0]),
-                     "+v"(nxt0[1]), "+v"(nxt0[2]), "+v"(nxt1[0]), "+v"(nxt1[1]), "+v"(nxt1[2]));
-      }
-#ifdef SLAMHIP_ABL_NO_GATHER
-    } else if (false) {
-#else
-    } else if (any) {
-#endif
-      // ---- D': gather straight from global memory, one pixel at a time ----
-#pragma unroll 1
-      for (int i = 0; i < STEPS; ++i) {
-        const int x0 = (int)(tap[i] & 0xffffu), y0 = (int)(tap[i] >> 16);
-        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-        Cells t;
-        t.a = global_cell(d2, c2, W, x0, y0); t.b = global_cell(d2, c2, W, x1, y0);
-        t.c = global_cell(d2, c2, W, x0, y1); t.e = global_cell(d2, c2, W, x1, y1);
-        unsigned int rgb[3];
-        load_rgb1(i, rgb);
-        const bool geo = blend_accumulate1<UNIT>(acc, t, fu[i], fv[i], (m_warp >> i) & 1u, factor_f, rgb, dd[i]);
-        m_geo |= geo ? (1u << i) : 0u;
-      }
-    }
-
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) n_geo += (unsigned int)__popcll(__ballot((m_geo >> i) & 1u));
-    __syncthreads();   // every gather of this half is done before the window is restaged
-    }  // halves
 
     // ---- reduce: DPP within the wave, LDS across the four waves, one atomic each ----
     const float t0 = wave_sum63(acc.ap.x + acc.ap.y), t1 = wave_sum63(acc.sp.x + acc.sp.y);
@@ -815,7 +798,7 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
       s_sum[wave][0] = t0; s_sum[wave][1] = t1; s_sum[wave][2] = t2; s_sum[wave][3] = t3;
       s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; s_cnt[wave][2] = n_warp; s_cnt[wave][3] = n_geo;
     }
-    __syncthreads();
+    __syncthreads();   // also: every gather is done before the next neighbour restages the window
     if (wave == 0) {
       PairAcc* pa = ws + bj;
       if (lane < 4) {
@@ -840,8 +823,7 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
         else if (lane == 8) atomicExch(&pa->ticket, 0u);
       }
     }
-    // s_box / s_sum / win are rewritten by the next neighbour only after every
-    // thread has passed the barrier above and the one after the bounding box
+    if (j + 1 < k) __syncthreads();   // s_sum / s_cnt are read before the next neighbour rewrites them
   }
 }
 
