@@ -154,6 +154,43 @@ def pair_loss(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR, out=None):
     return sums, counts
 
 
+class PairLossPlan(object):
+    """A prepared call of the fused kernel on fixed buffers: everything that does
+    not change between steps (argument checks, ctypes conversion, workspace and
+    output allocation) is done once, `run()` is a single C call.  Use it in
+    loops that process many batches of one shape; `rebind()` points the plan at
+    another set of input tensors of the same shape."""
+
+    def __init__(self, depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR, stream=None):
+        self._lib = capi.load()
+        self._fn = self._lib.slamhip_pair_loss_fused
+        self.K = capi.K4(K)
+        self.factor = float(factor)
+        self.stream = capi.current_stream() if stream is None else stream
+        self.rebind(depth1, rgb1, depth2, rgb2, rel)
+        dev = self._keep[0].device
+        self.sums = torch.empty((self.B, self.k, capi.NSUMS), dtype=torch.float64, device=dev)
+        self.counts = torch.empty((self.B, self.k, capi.NCOUNTS), dtype=torch.int32, device=dev)
+        nbytes = self._lib.slamhip_pair_loss_workspace_bytes(self.B, self.k)
+        self._ws = torch.zeros((max(nbytes, 64),), dtype=torch.uint8, device=dev)   # owned by this plan
+        self._tail = (self.sums.data_ptr(), self.counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self.stream)
+
+    def rebind(self, depth1, rgb1, depth2, rgb2, rel):
+        d1, c1, d2, c2, r, B, k, H, W = _pair_args(depth1, rgb1, depth2, rgb2, rel)
+        if hasattr(self, "B") and (B, k, H, W) != (self.B, self.k, self.H, self.W):
+            raise ValueError("rebind needs tensors of the plan's shape")
+        self.B, self.k, self.H, self.W = B, k, H, W
+        self._keep = (d1, c1, d2, c2, r)
+        self._head = (d1.data_ptr(), c1.data_ptr(), d2.data_ptr(), c2.data_ptr(), r.data_ptr())
+        return self
+
+    def run(self):
+        rc = self._fn(*self._head, self.K, self.factor, self.B, self.k, self.H, self.W, *self._tail)
+        if rc != 0:
+            capi.check(rc, "slamhip_pair_loss_fused")
+        return self.sums, self.counts
+
+
 def warp(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR):
     """Per-pixel outputs of the warp (materialising kernel); dict of tensors shaped
     [B,k,H,W(,C)]: warped_rgb, warped_depth, r_photo, r_geo, mask, iu_iv, uvd."""
