@@ -137,6 +137,88 @@ int slamhip_warp_materialize(const uint16_t* depth1, const uint8_t* rgb1, const 
                              float* warped_depth, float* r_photo, float* r_geo, uint8_t* mask,
                              int32_t* iu_iv, double* uvd, void* stream);
 
+/* ---- device: pose-regression encoder (bfloat16 operands, float32 accumulate) --
+ * Activations are NHWC bfloat16 (passed as void*); master parameters float32 in
+ * the reference's layouts: conv filters HWIO [3,3,Cin,Cout] (cnn_model.py:90-95),
+ * fully connected [in,out] (cnn_model.py:120-121). */
+
+/* slam/network/cnn_model.py:100-101 (tf.nn.conv2d, 3x3, stride 1, SAME) as an
+ * implicit GEMM on the matrix cores.  act [B,H,W,C] bf16; w_nk [N][9*C] bf16,
+ * element (n, tap*C + c) = filter[tap][c][n] (slamhip_conv_weight_layouts makes
+ * it); outputs [B,H,W,N] as bf16 and/or float32 (either may be NULL).
+ * flip=1 visits the taps in reverse: with w_nk = the [Cin][9*Cout] layout and
+ * act = dL/dout this is the gradient with respect to the input.  C % 64 == 0. */
+int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16, float* out_f32,
+                               int B, int H, int W, int C, int N, int flip, void* stream);
+
+/* cnn_model.py:74,123 (tf.matmul) - out[m][n] = sum_k a[m][k] * b[n][k]; a [M][K],
+ * b [N][K] bf16, K % 64 == 0. */
+int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, float* out_f32, int M,
+                         int N, int K, void* stream);
+
+/* Gradient of the filter (taps=9: dw [9][Cin][Cout], x [B,H,W,Cin], dy
+ * [B,H,W,Cout]) or of a fully connected weight (taps=1, H=W=1: dw = x^T dy,
+ * [Cin][Cout]); dw float32, overwritten.  What tf.gradients derives for
+ * cnn_model.py:100,123.  Cin % 64 == 0 and Cout % 64 == 0. */
+int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
+                       int Cout, int taps, void* stream);
+
+/* First layer of the network (cnn_model.py:38, Cin = 4): direct convolution and
+ * filter gradient from the float32 HWIO filter; Cout must divide 256 for the
+ * gradient. */
+int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, int H,
+                              int W, int Cin, int Cout, void* stream);
+int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W,
+                                int Cin, int Cout, void* stream);
+
+/* cnn_model.py:104-107 (tf.nn.moments over axes [0,1,2] +
+ * tf.nn.batch_normalization with the batch statistics, in training and in
+ * inference alike; biased variance).
+ * channel_stats: sums2c[c] = sum z, sums2c[C+c] = sum z^2 over the P rows of z
+ * [P][C] bf16 (float32 [2C], overwritten).  bn_relu_fwd: y = relu(gamma *
+ * (z - mean) / sqrt(var + eps) + beta) (cnn_model.py:107,113).  bn_relu_bwd: dz
+ * from dy through the ReLU and the normalisation, and red2c[c] = dbeta,
+ * red2c[C+c] = dgamma (float32 [2C], overwritten).  C % 64 == 0. */
+int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void* stream);
+int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta,
+                        void* y, long long P, int C, float eps, void* stream);
+int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const float* sums2c,
+                        const float* gamma, float* red2c, void* dz, long long P, int C, float eps,
+                        void* stream);
+
+/* cnn_model.py:123,74 / cnn_model_noBN.py (bias_add + relu) - y = act(z + bias) on a float32
+ * [M][N] product (relu=0: the linear output layer); backward: dz = dy * (y>0),
+ * dbias[n] = sum_m dz. */
+int slamhip_bias_act_fwd(const float* z, const float* bias, void* y_bf16, float* y_f32, int M,
+                         int N, int relu, void* stream);
+int slamhip_bias_act_bwd(const float* dy, const void* y_bf16, void* dz_bf16, float* dbias, int M,
+                         int N, int relu, void* stream);
+
+/* cnn_model.py:40,45,50,56,62 (tf.nn.max_pool 2x2, stride 2, VALID) and its gradient
+ * (to the first maximum of each window in row-major order).  C % 8 == 0. */
+int slamhip_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream);
+int slamhip_maxpool2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H,
+                         int W, int C, void* stream);
+
+/* Parameter casts / re-layouts into the operand forms above. */
+int slamhip_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
+int slamhip_transpose_cast_bf16(const float* src_rc, void* dst_cr, int R, int C, void* stream);
+int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad, int Cin, int Cout,
+                                void* stream);
+
+/* cnn_model.py:139-140 - loss[0] = tf.nn.l2_loss((out - gt) . loss_weight) =
+ * 0.5 * sum of squares; d_out (may be NULL) = its gradient with respect to out.
+ * out, gt [B][D] float32, loss_weight [D][D] row-major, D <= 8. */
+int slamhip_l2loss(const float* out, const float* gt, const float* loss_weight, float* loss,
+                   float* d_out, int B, int D, void* stream);
+
+/* cnn_model.py:162-166 - tf.train.AdamOptimizer update of one parameter tensor:
+ * g = grad * grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr * sqrt(1-b2^step)/(1-b1^step) * m / (sqrt(v) + eps).  step >= 1. */
+int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long long n, float lr,
+                      float beta1, float beta2, float eps, int step, float grad_scale,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,24 @@ SIGNATURES = {
     "slamhip_warp_materialize": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                   _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p], _c_int),
+    "slamhip_conv3x3_igemm_bf16": ([_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p], _c_int),
+    "slamhip_gemm_nt_bf16": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
+    "slamhip_wgrad_bf16": ([_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p], _c_int),
+    "slamhip_conv3x3_small_fwd": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p], _c_int),
+    "slamhip_conv3x3_small_wgrad": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p], _c_int),
+    "slamhip_channel_stats": ([_c_void_p, _c_void_p, ctypes.c_longlong, _c_int, _c_void_p], _c_int),
+    "slamhip_bn_relu_fwd": ([_c_void_p] * 5 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p], _c_int),
+    "slamhip_bn_relu_bwd": ([_c_void_p] * 7 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p], _c_int),
+    "slamhip_bias_act_fwd": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
+    "slamhip_bias_act_bwd": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
+    "slamhip_maxpool2_fwd": ([_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p], _c_int),
+    "slamhip_maxpool2_bwd": ([_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p], _c_int),
+    "slamhip_cast_f32_bf16": ([_c_void_p, _c_void_p, ctypes.c_longlong, _c_void_p], _c_int),
+    "slamhip_transpose_cast_bf16": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p], _c_int),
+    "slamhip_conv_weight_layouts": ([_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p], _c_int),
+    "slamhip_l2loss": ([_c_void_p] * 5 + [_c_int] * 2 + [_c_void_p], _c_int),
+    "slamhip_adam_step": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float,
+                                                                                          _c_void_p], _c_int),
 }
 
 _lib = None

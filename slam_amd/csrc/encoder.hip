@@ -1,0 +1,772 @@
+// Pose-regression encoder kernels for gfx950 (MI355X): the VGG16-style network
+// of slam/network/cnn_model.py:31-80 (conv3x3 SAME + batch-norm with batch
+// statistics + ReLU, 2x2 max-pool, two ReLU fully connected layers, linear
+// output), its weighted L2 loss (cnn_model.py:139-140) and Adam
+// (cnn_model.py:162-166, TensorFlow defaults).
+//
+// Layout: activations NHWC bf16; master parameters float32 in the reference's
+// layouts (conv HWIO [3,3,Cin,Cout], fc [in,out]); bf16 operand copies are made
+// per step in the K-contiguous layouts the MFMA kernels read.
+// The dense contractions (conv forward, data gradient, fully connected) are one
+// implicit-GEMM kernel on v_mfma_f32_32x32x16_bf16 with float32 accumulation;
+// the weight gradient is a second MFMA kernel that reads its pixel-major LDS
+// tiles through the transposing ds_read_b64_tr_b16.  Everything else is
+// bandwidth-bound elementwise / per-channel reduction code.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace slamhip {
+
+typedef __bf16 bf16;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short short4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int LDS_PITCH = 72;   // 64 bf16 of payload + 8 of padding per row (144 B)
+
+// ---------------------------------------------------------------------------
+// implicit GEMM:  out[m][n] = sum_{tap,c} A[pixel(m) + tap][c] * Bw[n][tap*C + c]
+// TAPS = 9: 3x3 SAME convolution over NHWC A (flip = 1 walks the taps backwards:
+//           the data gradient with Bw = the flipped, in/out-swapped filter)
+// TAPS = 1: plain NT GEMM, A [M][C], Bw [N][C]
+// ---------------------------------------------------------------------------
+template <int TAPS, int BN>
+__global__ void __launch_bounds__(256)
+igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
+                  float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip) {
+  constexpr int BM = 128;
+  constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
+  constexpr int BROWS_PER_PASS = 256 / 8;     // B loader: 8 threads (16 B each) cover one 64-element row
+  __shared__ __attribute__((aligned(16))) bf16 As[BM * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LDS_PITCH];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int Ktot = TAPS * C;
+
+  // A loader: thread -> row (pixel) tid>>1, 64-byte half tid&1
+  const int a_row = tid >> 1, a_half = tid & 1;
+  const int pm = m0 + a_row;
+  int pb = 0, py = 0, px = 0;
+  if (TAPS == 9) {
+    const int hw = H * W;
+    pb = pm / hw;
+    const int rem = pm - pb * hw;
+    py = rem / W;
+    px = rem - py * W;
+  }
+  // B loader: row tid>>3 (+32 per pass), 16-byte chunk tid&7
+  const int b_row = tid >> 3, b_chunk = tid & 7;
+
+  f32x16 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  const int ksteps = TAPS * (C / 64);
+  uint4 ra[4], rb[BN / BROWS_PER_PASS];
+
+  auto issue_loads = [&](int s) {
+    const int tap = s / (C / 64), c0 = (s - tap * (C / 64)) * 64;
+    const bf16* src = nullptr;
+    if (TAPS == 9) {
+      const int t = flip ? 8 - tap : tap;
+      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
+      if (pm < M && yy >= 0 && yy < H && xx >= 0 && xx < W)
+        src = A + ((long long)(pb * H + yy) * W + xx) * C + c0 + a_half * 32;
+    } else if (pm < M) {
+      src = A + (long long)pm * C + c0 + a_half * 32;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = src ? reinterpret_cast<const uint4*>(src)[i] : zero4;
+#pragma unroll
+    for (int i = 0; i < BN / BROWS_PER_PASS; ++i) {
+      const int n = n0 + b_row + i * BROWS_PER_PASS;
+      rb[i] = (n < N) ? *reinterpret_cast<const uint4*>(Bw + (long long)n * Ktot + tap * C + c0 + b_chunk * 8) : zero4;
+    }
+  };
+
+  issue_loads(0);
+  for (int s = 0; s < ksteps; ++s) {
+    __syncthreads();   // the previous step's fragments have been read
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<uint4*>(&As[a_row * LDS_PITCH + a_half * 32 + i * 8]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BN / BROWS_PER_PASS; ++i)
+      *reinterpret_cast<uint4*>(&Bs[(b_row + i * BROWS_PER_PASS) * LDS_PITCH + b_chunk * 8]) = rb[i];
+    __syncthreads();
+    if (s + 1 < ksteps) issue_loads(s + 1);   // in flight while the matrix cores work
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      bf16x8 af[2], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        af[i] = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&Bs[(wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+        if (m < M && n < N) {
+          const float v = acc[i][j][r];
+          if (out_bf16) out_bf16[(long long)m * N + n] = (bf16)v;
+          if (out_f32) out_f32[(long long)m * N + n] = v;
+        }
+      }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient:  dW[tap][ci][co] += sum_p X[pixel(p) + tap][ci] * dY[p][co]
+// (TAPS = 1: dW[ci][co] = X^T dY over the rows).  Both operands sit pixel-major
+// in LDS exactly as they come from HBM; the MFMA fragments (8 consecutive pixels
+// of one channel) are read with the transposing ds_read_b64_tr_b16.
+// Grid: (Cin/64, Cout/64, TAPS * splitk); each block adds its slice with
+// float32 atomics into the zeroed dW.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int mbase, int lane) {
+  // lanes 16g..16g+15: block of 4 pixel rows x 16 channels; lane 4q+p gives row q, channels 4p..4p+3
+  const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
+  const bf16* a0 = tile + (k0 + 8 * h + q) * LDS_PITCH + mbase + (g & 1) * 16 + 4 * p;
+  const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)a0);
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 4 * LDS_PITCH));
+  bf16x8 f;
+  const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f[j] = l4[j]; f[4 + j] = h4[j]; }
+  return f;
+}
+
+template <int TAPS>
+__global__ void __launch_bounds__(256)
+wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P, int Cin,
+                  int Cout, int H, int W, int splitk) {
+  __shared__ __attribute__((aligned(16))) bf16 Xs[64 * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[64 * LDS_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int tap = blockIdx.z / splitk, slice = blockIdx.z - tap * splitk;
+  const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
+  const int chunk = (P + splitk - 1) / splitk;
+  const int p_begin = slice * chunk, p_end = min(P, p_begin + chunk);
+
+  // loader: thread -> pixel row tid>>2 of the 64-pixel step, 32-byte quarter tid&3
+  const int l_row = tid >> 2, l_q = tid & 3;
+  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  uint4 rx[2], ry[2];
+
+  auto issue_loads = [&](int p0) {
+    const int p = p0 + l_row;
+    const bf16* xs = nullptr;
+    const bf16* ys = nullptr;
+    if (p < p_end) {
+      ys = dY + (long long)p * Cout + co0 + l_q * 16;
+      if (TAPS == 9) {
+        const int hw = H * W, b = p / hw, rem = p - b * hw, y = rem / W, x = rem - y * W;
+        const int yy = y + dy, xx = x + dx;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) xs = X + ((long long)(b * H + yy) * W + xx) * Cin + ci0 + l_q * 16;
+      } else {
+        xs = X + (long long)p * Cin + ci0 + l_q * 16;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      rx[i] = xs ? reinterpret_cast<const uint4*>(xs)[i] : zero4;
+      ry[i] = ys ? reinterpret_cast<const uint4*>(ys)[i] : zero4;
+    }
+  };
+
+  if (p_begin < p_end) issue_loads(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(&Xs[l_row * LDS_PITCH + l_q * 16 + i * 8]) = rx[i];
+      *reinterpret_cast<uint4*>(&Ys[l_row * LDS_PITCH + l_q * 16 + i * 8]) = ry[i];
+    }
+    __syncthreads();
+    if (p0 + 64 < p_end) issue_loads(p0 + 64);
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      const bf16x8 af = tr_frag(Xs, kk, wm * 32, lane);   // A[m = ci][k = pixel]
+      const bf16x8 bf = tr_frag(Ys, kk, wn * 32, lane);   // B[k = pixel][n = co]
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int co = co0 + wn * 32 + (lane & 31);
+    if (ci < Cin && co < Cout) {
+      float* dst = &dW[((long long)tap * Cin + ci) * Cout + co];
+      if (splitk == 1) *dst = acc[r];   // the only contribution: plain store, dW needs no zero-fill
+      else atomicAdd(dst, acc[r]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// first layer (Cin = 4, K = 36): too thin for the matrix cores, 0.8 % of the FLOPs
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+conv3x3_small_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt /*[3,3,Cin,Cout]*/,
+                         bf16* __restrict__ out, int P, int H, int W, int Cin, int Cout) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // over P * Cout
+  if (idx >= (long long)P * Cout) return;
+  const int co = (int)(idx % Cout);
+  const int p = (int)(idx / Cout);
+  const int hw = H * W, b = p / hw, rem = p - b * hw, y = rem / W, x = rem - y * W;
+  float acc = 0.0f;
+  for (int t = 0; t < 9; ++t) {
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    const bf16* xp = X + ((long long)(b * H + yy) * W + xx) * Cin;
+    for (int c = 0; c < Cin; ++c) acc = __builtin_fmaf((float)xp[c], Wt[(t * Cin + c) * Cout + co], acc);
+  }
+  out[idx] = (bf16)acc;
+}
+
+__global__ void __launch_bounds__(256)
+conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P,
+                           int H, int W, int Cin, int Cout) {
+  // one block per (tap, ci); thread = co; loops over a slice of the pixels
+  const int t = blockIdx.x / Cin, ci = blockIdx.x % Cin;
+  const int co = threadIdx.x % Cout, lanes_per_co = blockDim.x / Cout, sub = threadIdx.x / Cout;
+  const int slices = gridDim.y * lanes_per_co, slice = blockIdx.y * lanes_per_co + sub;
+  const int chunk = (P + slices - 1) / slices, p0 = slice * chunk, p1 = min(P, p0 + chunk);
+  const int hw = H * W;
+  float acc = 0.0f;
+  for (int p = p0; p < p1; ++p) {
+    const int b = p / hw, rem = p - b * hw, y = rem / W, x = rem - y * W;
+    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+    acc = __builtin_fmaf((float)X[((long long)(b * H + yy) * W + xx) * Cin + ci], (float)dY[(long long)p * Cout + co], acc);
+  }
+  atomicAdd(&dW[(t * Cin + ci) * Cout + co], acc);
+}
+
+// ---------------------------------------------------------------------------
+// per-channel statistics and batch-norm + ReLU (cnn_model.py:104-113; batch
+// statistics always, biased variance)
+// ---------------------------------------------------------------------------
+// sums[c] += sum_p z[p][c], sums[C + c] += sum_p z[p][c]^2.  Thread = channel pair
+// column, block walks a slice of rows; C is a multiple of 64.
+__global__ void __launch_bounds__(256)
+channel_stats_kernel(const bf16* __restrict__ z, float* __restrict__ sums, int P, int C) {
+  const int cols = C / 2;                       // channel pairs
+  const int per_block = 256 / min(cols, 256);   // row lanes per block when C < 512
+  const int col = threadIdx.x % cols, sub = threadIdx.x / cols;
+  if (sub >= per_block) return;
+  const int slices = gridDim.x * per_block, slice = blockIdx.x * per_block + sub;
+  const int chunk = (P + slices - 1) / slices, p0 = slice * chunk, p1 = min(P, p0 + chunk);
+  for (int cb = col; cb < cols; cb += 256) {
+    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(z + (long long)p * C + 2 * cb);
+      const float a = __uint_as_float(v << 16), b = __uint_as_float(v & 0xffff0000u);
+      s0 += a; s1 += b; q0 = __builtin_fmaf(a, a, q0); q1 = __builtin_fmaf(b, b, q1);
+    }
+    atomicAdd(&sums[2 * cb], s0); atomicAdd(&sums[2 * cb + 1], s1);
+    atomicAdd(&sums[C + 2 * cb], q0); atomicAdd(&sums[C + 2 * cb + 1], q1);
+  }
+}
+
+// y = relu(gamma * (z - mean) * rsqrt(var + eps) + beta), 8 channels per thread
+__global__ void __launch_bounds__(256)
+bn_relu_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ sums, const float* __restrict__ gamma,
+                   const float* __restrict__ beta, bf16* __restrict__ y, long long total8, int C, float inv_count,
+                   float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int c0 = (int)((i * 8) % C);
+  const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float mean = sums[c0 + j] * inv_count;
+    const float var = fmaxf(sums[C + c0 + j] * inv_count - mean * mean, 0.0f);
+    const float r = gamma[c0 + j] * rsqrtf(var + eps);
+    o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[j] - mean, r, beta[c0 + j]), 0.0f);
+  }
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+// backward reductions: red[c] += sum dyr, red[C + c] += sum dyr * xhat, dyr = dy * (y > 0)
+__global__ void __launch_bounds__(256)
+bn_relu_bwd_reduce_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ z,
+                          const float* __restrict__ sums, float* __restrict__ red, int P, int C, float inv_count,
+                          float eps) {
+  const int cols = min(C, 256), per_block = 256 / cols;
+  const int col = threadIdx.x % cols, sub = threadIdx.x / cols;
+  if (sub >= per_block) return;
+  const int slices = gridDim.x * per_block, slice = blockIdx.x * per_block + sub;
+  const int chunk = (P + slices - 1) / slices, p0 = slice * chunk, p1 = min(P, p0 + chunk);
+  for (int c = col; c < C; c += 256) {
+    const float mean = sums[c] * inv_count;
+    const float var = fmaxf(sums[C + c] * inv_count - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    float s = 0.f, sx = 0.f;
+    for (int p = p0; p < p1; ++p) {
+      const long long o = (long long)p * C + c;
+      const float g = ((float)y[o] > 0.0f) ? (float)dy[o] : 0.0f;
+      s += g;
+      sx = __builtin_fmaf(g, ((float)z[o] - mean) * rstd, sx);
+    }
+    atomicAdd(&red[c], s);
+    atomicAdd(&red[C + c], sx);
+  }
+}
+
+// dz = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat))
+__global__ void __launch_bounds__(256)
+bn_relu_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ z,
+                         const float* __restrict__ sums, const float* __restrict__ red,
+                         const float* __restrict__ gamma, bf16* __restrict__ dz, long long total8, int C,
+                         float inv_count, float eps) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int c0 = (int)((i * 8) % C);
+  const bf16x8 vdy = reinterpret_cast<const bf16x8*>(dy)[i], vy = reinterpret_cast<const bf16x8*>(y)[i],
+               vz = reinterpret_cast<const bf16x8*>(z)[i];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    const float mean = sums[c] * inv_count;
+    const float var = fmaxf(sums[C + c] * inv_count - mean * mean, 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    const float xhat = ((float)vz[j] - mean) * rstd;
+    const float g = ((float)vy[j] > 0.0f) ? (float)vdy[j] : 0.0f;
+    o[j] = (bf16)(gamma[c] * rstd * (g - red[c] * inv_count - xhat * red[C + c] * inv_count));
+  }
+  reinterpret_cast<bf16x8*>(dz)[i] = o;
+}
+
+// ---------------------------------------------------------------------------
+// bias + ReLU (cnn_model_noBN.py:109, cnn_model.py:123) and its backward
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+bias_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias, bf16* __restrict__ y_bf16,
+                    float* __restrict__ y_f32, long long total, int N, int relu) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  float v = z[i] + bias[i % N];
+  if (relu) v = fmaxf(v, 0.0f);
+  if (y_bf16) y_bf16[i] = (bf16)v;
+  if (y_f32) y_f32[i] = v;
+}
+
+// dz = dy * (y > 0) (relu) or dy; dbias[n] += sum_rows dz
+__global__ void __launch_bounds__(256)
+bias_act_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dz,
+                    float* __restrict__ dbias, int M, int N, int relu) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const long long o = (long long)m * N + n;
+    const float g = (!relu || (float)y[o] > 0.0f) ? dy[o] : 0.0f;
+    dz[o] = (bf16)g;
+    s += g;
+  }
+  dbias[n] = s;
+}
+
+// ---------------------------------------------------------------------------
+// 2x2 stride-2 VALID max-pool (cnn_model.py:40) and its backward (gradient to
+// the first maximum in row-major window order, like TensorFlow)
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+maxpool2_fwd_kernel(const bf16* __restrict__ x, bf16* __restrict__ y, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * Ho * Wo * C8) return;
+  const int c8 = (int)(i % C8);
+  long long r = i / C8;
+  const int xo = (int)(r % Wo); r /= Wo;
+  const int yo = (int)(r % Ho);
+  const int b = (int)(r / Ho);
+  const bf16x8* base = reinterpret_cast<const bf16x8*>(x + (((long long)b * H + 2 * yo) * W + 2 * xo) * C) + c8;
+  const bf16x8 v0 = base[0], v1 = base[C8], v2 = base[(long long)W * C8], v3 = base[(long long)W * C8 + C8];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(fmaxf((float)v0[j], (float)v1[j]), fmaxf((float)v2[j], (float)v3[j]));
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+__global__ void __launch_bounds__(256)
+maxpool2_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, const bf16* __restrict__ dy,
+                    bf16* __restrict__ dx, int B, int H, int W, int C) {
+  const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long long)B * Ho * Wo * C8) return;
+  const int c8 = (int)(i % C8);
+  long long r = i / C8;
+  const int xo = (int)(r % Wo); r /= Wo;
+  const int yo = (int)(r % Ho);
+  const int b = (int)(r / Ho);
+  const long long o00 = ((((long long)b * H + 2 * yo) * W + 2 * xo) * C) / 8 + c8;
+  const long long offs[4] = {o00, o00 + C8, o00 + (long long)W * C8, o00 + (long long)W * C8 + C8};
+  const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[i], vd = reinterpret_cast<const bf16x8*>(dy)[i];
+  bf16x8 in[4], out[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) in[q] = reinterpret_cast<const bf16x8*>(x)[offs[q]];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    bool taken = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool hit = !taken && ((float)in[q][j] == (float)vy[j]);
+      out[q][j] = hit ? vd[j] : (bf16)0.0f;
+      taken = taken || hit;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) reinterpret_cast<bf16x8*>(dx)[offs[q]] = out[q];
+  // odd trailing rows / columns of x (none for the 224 -> 7 chain) are zeroed by the caller
+}
+
+// ---------------------------------------------------------------------------
+// casts / re-layouts of the parameters
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (bf16)src[i];
+}
+
+// dst[c][r] = bf16(src[r][c]) for a row-major [R][Ccols] float matrix (32x32 LDS tiles)
+__global__ void __launch_bounds__(256)
+transpose_cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int Ccols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int j = ty; j < 32; j += 8)
+    if (r0 + j < R && c0 + tx < Ccols) tile[j][tx] = src[(long long)(r0 + j) * Ccols + c0 + tx];
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8)
+    if (c0 + j < Ccols && r0 + tx < R) dst[(long long)(c0 + j) * R + r0 + tx] = (bf16)tile[tx][j];
+}
+
+// conv filter HWIO [9][Cin][Cout] float -> forward operand [Cout][9*Cin] bf16 and
+// data-gradient operand [Cin][9*Cout] bf16 (taps stay in forward order; the
+// gradient kernel walks them backwards)
+__global__ void __launch_bounds__(256)
+conv_weight_layouts_kernel(const float* __restrict__ w, bf16* __restrict__ w_fwd, bf16* __restrict__ w_dgrad, int Cin,
+                           int Cout) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 9LL * Cin * Cout) return;
+  const int co = (int)(i % Cout);
+  const int ci = (int)((i / Cout) % Cin);
+  const int t = (int)(i / ((long long)Cout * Cin));
+  const bf16 v = (bf16)w[i];
+  if (w_fwd) w_fwd[(long long)co * 9 * Cin + t * Cin + ci] = v;
+  if (w_dgrad) w_dgrad[(long long)ci * 9 * Cout + t * Cout + co] = v;
+}
+
+// ---------------------------------------------------------------------------
+// loss (cnn_model.py:139-140): loss = 0.5 * sum(((out - gt) Wl)^2), d_out = ((out - gt) Wl) Wl^T
+// ---------------------------------------------------------------------------
+__global__ void l2loss_kernel(const float* __restrict__ out, const float* __restrict__ gt,
+                              const float* __restrict__ Wl, float* __restrict__ loss, float* __restrict__ d_out,
+                              int Bn, int D) {
+  // one block; D <= 8
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < Bn; b += blockDim.x) {
+    float e[8], r[8];
+    for (int i = 0; i < D; ++i) e[i] = out[b * D + i] - gt[b * D + i];
+    for (int j = 0; j < D; ++j) {
+      float s = 0.f;
+      for (int i = 0; i < D; ++i) s = __builtin_fmaf(e[i], Wl[i * D + j], s);
+      r[j] = s;
+      acc = __builtin_fmaf(s, s, acc);
+    }
+    if (d_out)
+      for (int i = 0; i < D; ++i) {
+        float s = 0.f;
+        for (int j = 0; j < D; ++j) s = __builtin_fmaf(r[j], Wl[i * D + j], s);
+        d_out[b * D + i] = s;
+      }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = 0.5f * part[0];
+}
+
+// ---------------------------------------------------------------------------
+// Adam (TensorFlow AdamOptimizer defaults: beta1 0.9, beta2 0.999, eps 1e-8;
+// lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)); grad_scale folds the 1/world
+// of the data-parallel mean
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+            long long n, float lr_t, float beta1, float beta2, float eps, float grad_scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+  const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+}
+
+static unsigned int blocks_for(long long n, int per = 256) { return (unsigned int)((n + per - 1) / per); }
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+extern "C" {
+
+int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16, float* out_f32, int B, int H,
+                               int W, int C, int N, int flip, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && C > 0 && N > 0, SLAMHIP_E_ARG, "conv3x3_igemm: bad shape");
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(act && w_nk && (out_bf16 || out_f32), SLAMHIP_E_ARG, "conv3x3_igemm: null pointer");
+  SLAMHIP_REQUIRE(C % 64 == 0, SLAMHIP_E_SIZE, "conv3x3_igemm: channels per tap (%d) must be a multiple of 64", C);
+  const long long M = (long long)B * H * W;
+  SLAMHIP_REQUIRE(M <= 0x7fffffffLL, SLAMHIP_E_SIZE, "conv3x3_igemm: too many pixels");
+  hipStream_t s = (hipStream_t)stream;
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((igemm_bf16_kernel<9, 128>), dim3((unsigned)((M + 127) / 128), N / 128), dim3(256), 0, s,
+                       (const bf16*)act, (const bf16*)w_nk, (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip);
+  else
+    hipLaunchKernelGGL((igemm_bf16_kernel<9, 64>), dim3((unsigned)((M + 127) / 128), (N + 63) / 64), dim3(256), 0, s,
+                       (const bf16*)act, (const bf16*)w_nk, (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, float* out_f32, int M, int N, int K,
+                         void* stream) {
+  SLAMHIP_REQUIRE(M >= 0 && N > 0 && K > 0, SLAMHIP_E_ARG, "gemm_nt: bad shape");
+  if (M == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(a_mk && b_nk && (out_bf16 || out_f32), SLAMHIP_E_ARG, "gemm_nt: null pointer");
+  SLAMHIP_REQUIRE(K % 64 == 0, SLAMHIP_E_SIZE, "gemm_nt: K (%d) must be a multiple of 64", K);
+  hipStream_t s = (hipStream_t)stream;
+  if (N % 128 == 0)
+    hipLaunchKernelGGL((igemm_bf16_kernel<1, 128>), dim3((M + 127) / 128, N / 128), dim3(256), 0, s, (const bf16*)a_mk,
+                       (const bf16*)b_nk, (bf16*)out_bf16, out_f32, M, N, K, 1, 1, 0);
+  else
+    hipLaunchKernelGGL((igemm_bf16_kernel<1, 64>), dim3((M + 127) / 128, (N + 63) / 64), dim3(256), 0, s,
+                       (const bf16*)a_mk, (const bf16*)b_nk, (bf16*)out_bf16, out_f32, M, N, K, 1, 1, 0);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout, int taps,
+                       void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && (taps == 1 || taps == 9), SLAMHIP_E_ARG,
+                  "wgrad: bad shape");
+  SLAMHIP_REQUIRE(x && dy && dw, SLAMHIP_E_ARG, "wgrad: null pointer");
+  SLAMHIP_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, SLAMHIP_E_SIZE, "wgrad: channels must be multiples of 64");
+  hipStream_t s = (hipStream_t)stream;
+  const long long P = (long long)B * H * W;
+  SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "wgrad: too many pixels");
+  const long long tiles = (long long)(Cin / 64) * (Cout / 64) * taps;
+  long long splitk = (2048 + tiles - 1) / tiles;                      // aim at >= 2048 workgroups
+  const long long max_split = (P + 255) / 256;                          // at least 256 pixels per slice
+  if (splitk > max_split) splitk = max_split;
+  if (splitk < 1) splitk = 1;
+  if (taps * splitk > 65535) splitk = 65535 / taps;
+  if (splitk != 1 || P == 0) SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)taps * Cin * Cout, s));
+  if (P == 0) return SLAMHIP_OK;
+  const dim3 grid(Cin / 64, Cout / 64, (unsigned)(taps * splitk));
+  if (taps == 9)
+    hipLaunchKernelGGL(wgrad_bf16_kernel<9>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, (int)P, Cin,
+                       Cout, H, W, (int)splitk);
+  else
+    hipLaunchKernelGGL(wgrad_bf16_kernel<1>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, (int)P, Cin,
+                       Cout, H, W, (int)splitk);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, int H, int W, int Cin,
+                              int Cout, void* stream) {
+  SLAMHIP_REQUIRE(x && w_hwio && out_bf16 && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, SLAMHIP_E_ARG,
+                  "conv3x3_small_fwd: bad argument");
+  const long long total = (long long)B * H * W * Cout;
+  if (total == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)x, w_hwio, (bf16*)out_bf16, B * H * W, H, W, Cin, Cout);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                                void* stream) {
+  SLAMHIP_REQUIRE(x && dy && dw && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= 256 && 256 % Cout == 0,
+                  SLAMHIP_E_ARG, "conv3x3_small_wgrad: bad argument (Cout must divide 256)");
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+  if (B == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
+                     dw, B * H * W, H, W, Cin, Cout);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void* stream) {
+  SLAMHIP_REQUIRE(z && sums2c && P >= 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG, "channel_stats: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(sums2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  if (P == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
+  const unsigned grid = (unsigned)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)z, sums2c, (int)P, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta, void* y,
+                        long long P, int C, float eps, void* stream) {
+  SLAMHIP_REQUIRE(z && sums2c && gamma && beta && y && P > 0 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG,
+                  "bn_relu_fwd: bad argument");
+  const long long total8 = P * C / 8;
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(total8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z,
+                     sums2c, gamma, beta, (bf16*)y, total8, C, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const float* sums2c, const float* gamma,
+                        float* red2c, void* dz, long long P, int C, float eps, void* stream) {
+  SLAMHIP_REQUIRE(dy && y && z && sums2c && gamma && red2c && dz && P > 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG,
+                  "bn_relu_bwd: bad argument");
+  SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_bwd: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  const unsigned grid = (unsigned)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
+                     (const bf16*)z, sums2c, red2c, (int)P, C, 1.0f / (float)P, eps);
+  const long long total8 = P * C / 8;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy,
+                     (const bf16*)y, (const bf16*)z, sums2c, red2c, gamma, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bias_act_fwd(const float* z, const float* bias, void* y_bf16, float* y_f32, int M, int N, int relu,
+                         void* stream) {
+  SLAMHIP_REQUIRE(z && bias && (y_bf16 || y_f32) && M >= 0 && N > 0, SLAMHIP_E_ARG, "bias_act_fwd: bad argument");
+  const long long total = (long long)M * N;
+  if (total == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(bias_act_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, z, bias,
+                     (bf16*)y_bf16, y_f32, total, N, relu);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bias_act_bwd(const float* dy, const void* y_bf16, void* dz_bf16, float* dbias, int M, int N, int relu,
+                         void* stream) {
+  SLAMHIP_REQUIRE(dy && dz_bf16 && dbias && (y_bf16 || !relu) && M >= 0 && N > 0, SLAMHIP_E_ARG,
+                  "bias_act_bwd: bad argument");
+  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, (hipStream_t)stream, dy,
+                     (const bf16*)y_bf16, (bf16*)dz_bf16, dbias, M, N, relu);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_maxpool2_fwd(const void* x, void* y, int B, int H, int W, int C, void* stream) {
+  SLAMHIP_REQUIRE(x && y && B >= 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG, "maxpool2_fwd: bad argument");
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  if (total == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream, (const bf16*)x,
+                     (bf16*)y, B, H, W, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_maxpool2_bwd(const void* x, const void* y, const void* dy, void* dx, int B, int H, int W, int C,
+                         void* stream) {
+  SLAMHIP_REQUIRE(x && y && dy && dx && B >= 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG,
+                  "maxpool2_bwd: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  if ((H & 1) || (W & 1)) SLAMHIP_HIP(hipMemsetAsync(dx, 0, 2 * (size_t)B * H * W * C, s));
+  const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
+  if (total == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16*)x, (const bf16*)y,
+                     (const bf16*)dy, (bf16*)dx, B, H, W, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_cast_f32_bf16(const float* src, void* dst, long long n, void* stream) {
+  SLAMHIP_REQUIRE(src && dst && n >= 0, SLAMHIP_E_ARG, "cast_f32_bf16: bad argument");
+  if (n == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_transpose_cast_bf16(const float* src_rc, void* dst_cr, int R, int C, void* stream) {
+  SLAMHIP_REQUIRE(src_rc && dst_cr && R > 0 && C > 0, SLAMHIP_E_ARG, "transpose_cast: bad argument");
+  hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                     src_rc, (bf16*)dst_cr, R, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad, int Cin, int Cout, void* stream) {
+  SLAMHIP_REQUIRE(w_hwio && (w_fwd || w_dgrad) && Cin > 0 && Cout > 0, SLAMHIP_E_ARG, "conv_weight_layouts: bad argument");
+  hipLaunchKernelGGL(conv_weight_layouts_kernel, dim3(blocks_for(9LL * Cin * Cout)), dim3(256), 0,
+                     (hipStream_t)stream, w_hwio, (bf16*)w_fwd, (bf16*)w_dgrad, Cin, Cout);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_l2loss(const float* out, const float* gt, const float* loss_weight, float* loss, float* d_out, int B, int D,
+                   void* stream) {
+  SLAMHIP_REQUIRE(out && gt && loss_weight && loss && B >= 0 && D > 0 && D <= 8, SLAMHIP_E_ARG,
+                  "l2loss: bad argument (output width must be <= 8)");
+  hipLaunchKernelGGL(l2loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, gt, loss_weight, loss, d_out, B, D);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,
+                      float beta2, float eps, int step, float grad_scale, void* stream) {
+  SLAMHIP_REQUIRE(param && grad && m && v && n >= 0 && step >= 1, SLAMHIP_E_ARG, "adam_step: bad argument");
+  if (n == 0) return SLAMHIP_OK;
+  const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
+                     beta1, beta2, eps, grad_scale);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

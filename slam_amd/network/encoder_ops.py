@@ -1,0 +1,178 @@
+"""Typed wrappers of the encoder entry points of libslamhip.so.
+
+Every function takes torch tensors that already live on the GPU (torch owns the
+memory and the stream, nothing else), checks shapes/dtypes on the host so a
+wrong call cannot reach a kernel, and launches on the current stream.
+Activations are NHWC bfloat16; parameters float32 in the reference's layouts
+(slam/network/cnn_model.py:90-95, 120-121).
+"""
+import torch
+
+from .. import capi
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
+def _chk(t, dtype, what):
+    if t.dtype != dtype or not t.is_contiguous() or not t.is_cuda:
+        raise ValueError("%s: expected a contiguous %s GPU tensor, got %s %s contiguous=%s" %
+                         (what, dtype, t.dtype, t.device, t.is_contiguous()))
+    return t
+
+
+def _call(name, *args):
+    capi.check(getattr(capi.load(), name)(*args, capi.current_stream()), name)
+
+
+def conv_weight_layouts(w_hwio, w_fwd=None, w_dgrad=None):
+    """[3,3,Cin,Cout] float32 -> [Cout, 9*Cin] and/or [Cin, 9*Cout] bfloat16 operands."""
+    _chk(w_hwio, F32, "w_hwio")
+    kh, kw, cin, cout = w_hwio.shape
+    assert (kh, kw) == (3, 3)
+    if w_fwd is not None:
+        assert _chk(w_fwd, BF16, "w_fwd").shape == (cout, 9 * cin)
+    if w_dgrad is not None:
+        assert _chk(w_dgrad, BF16, "w_dgrad").shape == (cin, 9 * cout)
+    _call("slamhip_conv_weight_layouts", capi.ptr(w_hwio), capi.ptr(w_fwd), capi.ptr(w_dgrad), cin, cout)
+
+
+def conv3x3(act, w_nk, out_bf16=None, out_f32=None, flip=False):
+    """3x3 SAME convolution (flip=False) or its input gradient (flip=True)."""
+    _chk(act, BF16, "act")
+    B, H, W, C = act.shape
+    N = _chk(w_nk, BF16, "w_nk").shape[0]
+    assert w_nk.shape == (N, 9 * C) and C % 64 == 0
+    for o, dt in ((out_bf16, BF16), (out_f32, F32)):
+        if o is not None:
+            assert _chk(o, dt, "out").shape == (B, H, W, N)
+    _call("slamhip_conv3x3_igemm_bf16", capi.ptr(act), capi.ptr(w_nk), capi.ptr(out_bf16), capi.ptr(out_f32),
+          B, H, W, C, N, int(flip))
+
+
+def gemm_nt(a, b, out_bf16=None, out_f32=None):
+    """out[m, n] = sum_k a[m, k] * b[n, k]."""
+    M, K = _chk(a, BF16, "a").shape
+    N = _chk(b, BF16, "b").shape[0]
+    assert b.shape == (N, K) and K % 64 == 0
+    for o, dt in ((out_bf16, BF16), (out_f32, F32)):
+        if o is not None:
+            assert _chk(o, dt, "out").shape == (M, N)
+    _call("slamhip_gemm_nt_bf16", capi.ptr(a), capi.ptr(b), capi.ptr(out_bf16), capi.ptr(out_f32), M, N, K)
+
+
+def wgrad(x, dy, dw):
+    """Filter gradient [3,3,Cin,Cout] (4-d x) or x^T dy [Cin,Cout] (2-d x), float32."""
+    _chk(x, BF16, "x"), _chk(dy, BF16, "dy"), _chk(dw, F32, "dw")
+    if x.dim() == 4:
+        B, H, W, cin = x.shape
+        cout = dy.shape[3]
+        assert dy.shape == (B, H, W, cout) and dw.shape == (3, 3, cin, cout)
+        taps = 9
+    else:
+        B, cin = x.shape
+        cout = dy.shape[1]
+        assert dy.shape == (B, cout) and dw.shape == (cin, cout)
+        H = W = taps = 1
+    assert cin % 64 == 0 and cout % 64 == 0
+    _call("slamhip_wgrad_bf16", capi.ptr(x), capi.ptr(dy), capi.ptr(dw), B, H, W, cin, cout, taps)
+
+
+def conv3x3_small(x, w_hwio, out):
+    B, H, W, cin = _chk(x, BF16, "x").shape
+    cout = _chk(w_hwio, F32, "w").shape[3]
+    assert w_hwio.shape == (3, 3, cin, cout) and _chk(out, BF16, "out").shape == (B, H, W, cout)
+    _call("slamhip_conv3x3_small_fwd", capi.ptr(x), capi.ptr(w_hwio), capi.ptr(out), B, H, W, cin, cout)
+
+
+def conv3x3_small_wgrad(x, dy, dw):
+    B, H, W, cin = _chk(x, BF16, "x").shape
+    cout = _chk(dy, BF16, "dy").shape[3]
+    assert dy.shape == (B, H, W, cout) and _chk(dw, F32, "dw").shape == (3, 3, cin, cout) and 256 % cout == 0
+    _call("slamhip_conv3x3_small_wgrad", capi.ptr(x), capi.ptr(dy), capi.ptr(dw), B, H, W, cin, cout)
+
+
+def channel_stats(z, sums2c):
+    C = _chk(z, BF16, "z").shape[-1]
+    P = z.numel() // C
+    assert _chk(sums2c, F32, "sums").shape == (2, C) and C % 64 == 0
+    _call("slamhip_channel_stats", capi.ptr(z), capi.ptr(sums2c), P, C)
+
+
+def bn_relu(z, sums2c, gamma, beta, y, eps):
+    C = _chk(z, BF16, "z").shape[-1]
+    P = z.numel() // C
+    assert _chk(y, BF16, "y").shape == z.shape and sums2c.shape == (2, C)
+    assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
+    _call("slamhip_bn_relu_fwd", capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y), P, C,
+          float(eps))
+
+
+def bn_relu_bwd(dy, y, z, sums2c, gamma, red2c, dz, eps):
+    """dz, and red2c[0] = dbeta, red2c[1] = dgamma."""
+    C = _chk(z, BF16, "z").shape[-1]
+    P = z.numel() // C
+    for t in (dy, y, dz):
+        assert _chk(t, BF16, "bn tensor").shape == z.shape
+    assert _chk(red2c, F32, "red").shape == (2, C) and sums2c.shape == (2, C) and gamma.shape == (C,)
+    _call("slamhip_bn_relu_bwd", capi.ptr(dy), capi.ptr(y), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma),
+          capi.ptr(red2c), capi.ptr(dz), P, C, float(eps))
+
+
+def bias_act(z, bias, y_bf16=None, y_f32=None, relu=True):
+    M, N = _chk(z, F32, "z").shape
+    assert _chk(bias, F32, "bias").shape == (N,)
+    for o, dt in ((y_bf16, BF16), (y_f32, F32)):
+        if o is not None:
+            assert _chk(o, dt, "y").shape == (M, N)
+    _call("slamhip_bias_act_fwd", capi.ptr(z), capi.ptr(bias), capi.ptr(y_bf16), capi.ptr(y_f32), M, N, int(relu))
+
+
+def bias_act_bwd(dy, y_bf16, dz, dbias, relu=True):
+    M, N = _chk(dy, F32, "dy").shape
+    assert _chk(dz, BF16, "dz").shape == (M, N) and _chk(dbias, F32, "dbias").shape == (N,)
+    if relu:
+        assert _chk(y_bf16, BF16, "y").shape == (M, N)
+    _call("slamhip_bias_act_bwd", capi.ptr(dy), capi.ptr(y_bf16) if relu else None, capi.ptr(dz), capi.ptr(dbias),
+          M, N, int(relu))
+
+
+def maxpool2(x, y):
+    B, H, W, C = _chk(x, BF16, "x").shape
+    assert _chk(y, BF16, "y").shape == (B, H // 2, W // 2, C) and C % 8 == 0
+    _call("slamhip_maxpool2_fwd", capi.ptr(x), capi.ptr(y), B, H, W, C)
+
+
+def maxpool2_bwd(x, y, dy, dx):
+    B, H, W, C = _chk(x, BF16, "x").shape
+    assert _chk(y, BF16, "y").shape == (B, H // 2, W // 2, C) and _chk(dy, BF16, "dy").shape == y.shape
+    assert _chk(dx, BF16, "dx").shape == x.shape
+    _call("slamhip_maxpool2_bwd", capi.ptr(x), capi.ptr(y), capi.ptr(dy), capi.ptr(dx), B, H, W, C)
+
+
+def cast_bf16(src, dst):
+    assert _chk(src, F32, "src").numel() == _chk(dst, BF16, "dst").numel()
+    _call("slamhip_cast_f32_bf16", capi.ptr(src), capi.ptr(dst), src.numel())
+
+
+def transpose_cast(src, dst):
+    R, C = _chk(src, F32, "src").shape
+    assert _chk(dst, BF16, "dst").shape == (C, R)
+    _call("slamhip_transpose_cast_bf16", capi.ptr(src), capi.ptr(dst), R, C)
+
+
+def l2loss(out, gt, loss_weight, loss, d_out=None):
+    B, D = _chk(out, F32, "out").shape
+    assert _chk(gt, F32, "gt").shape == (B, D) and _chk(loss_weight, F32, "loss_weight").shape == (D, D)
+    assert _chk(loss, F32, "loss").numel() == 1 and D <= 8
+    if d_out is not None:
+        assert _chk(d_out, F32, "d_out").shape == (B, D)
+    _call("slamhip_l2loss", capi.ptr(out), capi.ptr(gt), capi.ptr(loss_weight), capi.ptr(loss), capi.ptr(d_out), B, D)
+
+
+def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    n = _chk(param, F32, "param").numel()
+    for t in (grad, m, v):
+        assert _chk(t, F32, "adam tensor").numel() == n
+    _call("slamhip_adam_step", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, float(lr), float(beta1),
+          float(beta2), float(eps), int(step), float(grad_scale))

@@ -1,0 +1,219 @@
+"""GPU parity of the encoder kernels (through the C ABI) against plain PyTorch
+float32 on the CPU.  Inputs are rounded to bfloat16 first, so the only
+differences are the float32 accumulation order and the final bfloat16 rounding
+of outputs (2^-8 relative).  The reference's own numerics (TensorFlow 0.x, its
+weights file) are not available: this parity is unpinned by the reference and
+anchored on the operator definitions of slam/network/cnn_model.py:100-123.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slam_amd.network import encoder_ops
+    return encoder_ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF).float()
+
+
+def close(got, want, rtol=1.5e-2, atol=None):
+    got = got.detach().float().cpu()
+    want = want.detach().float()
+    atol = atol if atol is not None else rtol * float(want.abs().max() + 1e-12)
+    err = (got - want).abs()
+    assert torch.all(err <= atol + rtol * want.abs()), "max err %g (ref max %g)" % (float(err.max()), float(want.abs().max()))
+
+
+def conv_ref(x_nhwc, w_hwio):
+    return F.conv2d(x_nhwc.permute(0, 3, 1, 2), w_hwio.permute(3, 2, 0, 1), padding=1).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 9, 11, 64, 64), (1, 14, 14, 128, 128), (3, 7, 5, 64, 256), (1, 4, 4, 192, 64)])
+def test_conv_fwd_dgrad_wgrad(ops, B, H, W, C, N):
+    x = rnd(B, H, W, C, seed=1).requires_grad_()
+    w = rnd(3, 3, C, N, seed=2, scale=0.05).requires_grad_()
+    y = conv_ref(x, w)
+    dy = rnd(B, H, W, N, seed=3)
+    y.backward(dy)
+    dev = "cuda"
+    xd, wd, dyd = x.detach().to(dev).to(BF), w.detach().to(dev), dy.to(dev).to(BF)
+    w_fwd = torch.empty(N, 9 * C, dtype=BF, device=dev)
+    w_dg = torch.empty(C, 9 * N, dtype=BF, device=dev)
+    ops.conv_weight_layouts(wd, w_fwd, w_dg)
+    out_b = torch.empty(B, H, W, N, dtype=BF, device=dev)
+    out_f = torch.empty(B, H, W, N, dtype=torch.float32, device=dev)
+    ops.conv3x3(xd, w_fwd, out_b, out_f)
+    close(out_f, y, rtol=2e-3)
+    close(out_b, y)
+    if N % 64 == 0:
+        dx = torch.empty(B, H, W, C, dtype=BF, device=dev)
+        ops.conv3x3(dyd, w_dg, dx, None, flip=True)
+        close(dx, x.grad)
+        dw = torch.full((3, 3, C, N), 7.0, dtype=torch.float32, device=dev)
+        ops.wgrad(xd, dyd, dw)
+        close(dw, w.grad, rtol=2e-3)
+
+
+def test_wgrad_many_pixels_splitk(ops):
+    B, H, W, C, N = 4, 32, 32, 64, 64
+    x = rnd(B, H, W, C, seed=4).requires_grad_()
+    w = rnd(3, 3, C, N, seed=5, scale=0.05).requires_grad_()
+    dy = rnd(B, H, W, N, seed=6)
+    conv_ref(x, w).backward(dy)
+    dw = torch.empty(3, 3, C, N, dtype=torch.float32, device="cuda")
+    ops.wgrad(x.detach().cuda().to(BF), dy.cuda().to(BF), dw)
+    close(dw, w.grad, rtol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(5, 6, 128), (130, 256, 192), (128, 64, 64), (1, 4096, 256)])
+def test_gemm_nt_and_fc_wgrad(ops, M, N, K):
+    a, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.1)
+    want = a @ b.t()
+    out_f = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    out_b = torch.empty(M, N, dtype=BF, device="cuda")
+    ops.gemm_nt(a.cuda().to(BF), b.cuda().to(BF), out_b, out_f)
+    close(out_f, want, rtol=2e-3)
+    close(out_b, want)
+    if N % 64 == 0:
+        dy = rnd(M, N, seed=9)
+        dw = torch.empty(K, N, dtype=torch.float32, device="cuda")
+        ops.wgrad(a.cuda().to(BF), dy.cuda().to(BF), dw)
+        close(dw, a.t() @ dy, rtol=2e-3)
+
+
+def test_first_layer(ops):
+    B, H, W, C, N = 2, 10, 12, 4, 64
+    x = rnd(B, H, W, C, seed=10).requires_grad_()
+    w = rnd(3, 3, C, N, seed=11, scale=0.05).requires_grad_()
+    y = conv_ref(x, w)
+    dy = rnd(B, H, W, N, seed=12)
+    y.backward(dy)
+    out = torch.empty(B, H, W, N, dtype=BF, device="cuda")
+    xd = x.detach().cuda().to(BF)
+    ops.conv3x3_small(xd, w.detach().cuda(), out)
+    close(out, y)
+    dw = torch.empty(3, 3, C, N, dtype=torch.float32, device="cuda")
+    ops.conv3x3_small_wgrad(xd, dy.cuda().to(BF), dw)
+    close(dw, w.grad, rtol=2e-3)
+
+
+@pytest.mark.parametrize("P_shape,C", [((2, 6, 6), 64), ((3, 5, 7), 128), ((1, 3, 3), 512)])
+def test_batchnorm_relu(ops, P_shape, C):
+    eps = 1e-3
+    z = rnd(*P_shape, C, seed=13).requires_grad_()
+    gamma = (1.0 + 0.1 * rnd(C, seed=14)).requires_grad_()
+    beta = (0.1 * rnd(C, seed=15)).requires_grad_()
+    mean = z.mean(dim=(0, 1, 2))
+    var = z.var(dim=(0, 1, 2), unbiased=False)
+    y = torch.relu((z - mean) * torch.rsqrt(var + eps) * gamma + beta)
+    dy = rnd(*P_shape, C, seed=16)
+    y.backward(dy)
+    dev = "cuda"
+    zd = z.detach().to(dev).to(BF)
+    sums = torch.empty(2, C, dtype=torch.float32, device=dev)
+    ops.channel_stats(zd, sums)
+    n = z.numel() // C
+    close(sums[0] / n, mean, rtol=1e-4, atol=1e-5)
+    close(sums[1] / n - (sums[0] / n) ** 2, var, rtol=1e-3)
+    yd = torch.empty_like(zd)
+    ops.bn_relu(zd, sums, gamma.detach().to(dev), beta.detach().to(dev), yd, eps)
+    close(yd, y)
+    # the backward kernel gates on the stored bfloat16 y: feed the reference's own mask
+    # through the same rounding by using yd as produced above
+    red = torch.empty(2, C, dtype=torch.float32, device=dev)
+    dz = torch.empty_like(zd)
+    ops.bn_relu_bwd(dy.to(dev).to(BF), yd, zd, sums, gamma.detach().to(dev), red, dz, eps)
+    close(red[0], beta.grad, rtol=5e-3)
+    close(red[1], gamma.grad, rtol=5e-3)
+    close(dz, z.grad, rtol=2e-2)
+
+
+def test_maxpool(ops):
+    B, H, W, C = 2, 6, 8, 64
+    x = rnd(B, H, W, C, seed=17).requires_grad_()
+    y = F.max_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    dy = rnd(B, H // 2, W // 2, C, seed=18)
+    y.backward(dy)
+    xd = x.detach().cuda().to(BF)
+    yd = torch.empty(B, H // 2, W // 2, C, dtype=BF, device="cuda")
+    ops.maxpool2(xd, yd)
+    assert torch.equal(yd.float().cpu(), y.detach())
+    dx = torch.empty_like(xd)
+    ops.maxpool2_bwd(xd, yd, dy.cuda().to(BF), dx)
+    assert torch.equal(dx.float().cpu(), x.grad)
+
+
+def test_maxpool_ties_go_to_first(ops):
+    x = torch.ones(1, 2, 2, 8, dtype=BF, device="cuda")
+    y = torch.empty(1, 1, 1, 8, dtype=BF, device="cuda")
+    ops.maxpool2(x, y)
+    dx = torch.empty_like(x)
+    ops.maxpool2_bwd(x, y, torch.full_like(y, 3.0), dx)
+    assert torch.equal(dx.float().cpu().reshape(4, 8)[:, 0], torch.tensor([3.0, 0.0, 0.0, 0.0]))
+
+
+def test_bias_act_loss_adam_casts(ops):
+    M, N = 7, 128
+    z, b = rnd(M, N, seed=19), rnd(N, seed=20)
+    yb = torch.empty(M, N, dtype=BF, device="cuda")
+    yf = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    ops.bias_act(z.cuda(), b.cuda(), yb, yf, relu=True)
+    want = torch.relu(z + b)
+    close(yf, want, rtol=1e-6)
+    close(yb, want)
+    dy = rnd(M, N, seed=21)
+    dz = torch.empty(M, N, dtype=BF, device="cuda")
+    db = torch.empty(N, dtype=torch.float32, device="cuda")
+    ops.bias_act_bwd(dy.cuda(), yb, dz, db, relu=True)
+    g = dy * (want > 0)
+    close(dz, g)
+    close(db, g.sum(0), rtol=1e-5)
+    ops.bias_act_bwd(dy.cuda(), None, dz, db, relu=False)
+    close(db, dy.sum(0), rtol=1e-5)
+
+    # loss: 0.5 * sum(((out - gt) Wl)^2) and its gradient
+    Bn, D = 9, 6
+    out = rnd(Bn, D, seed=22).requires_grad_()
+    gt, Wl = rnd(Bn, D, seed=23), rnd(D, D, seed=24)
+    loss = 0.5 * (((out - gt) @ Wl) ** 2).sum()
+    loss.backward()
+    ld = torch.empty(1, dtype=torch.float32, device="cuda")
+    dod = torch.empty(Bn, D, dtype=torch.float32, device="cuda")
+    ops.l2loss(out.detach().cuda(), gt.cuda(), Wl.cuda(), ld, dod)
+    close(ld, loss.reshape(1), rtol=1e-5)
+    close(dod, out.grad, rtol=1e-4)
+
+    # Adam against torch.optim.Adam (same update rule as TensorFlow's up to where eps enters;
+    # checked against the TensorFlow formula written out)
+    n = 1000
+    p0, g0 = rnd(n, seed=25), rnd(n, seed=26)
+    p, m, v = p0.clone().cuda(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pr, mr, vr = p0.clone().double(), torch.zeros(n).double(), torch.zeros(n).double()
+    for step in (1, 2, 3):
+        g = g0 * step
+        ops.adam_step(p, g.cuda(), m, v, lr=0.01, step=step)
+        mr = 0.9 * mr + 0.1 * g.double()
+        vr = 0.999 * vr + 0.001 * g.double() ** 2
+        lr_t = 0.01 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        pr = pr - lr_t * mr / (vr.sqrt() + 1e-8)
+    close(p, pr.float(), rtol=1e-5)
+
+    src = rnd(37, 70, seed=27)
+    dst = torch.empty(70, 37, dtype=BF, device="cuda")
+    ops.transpose_cast(src.cuda(), dst)
+    assert torch.equal(dst.float().cpu(), src.t())
+    dst2 = torch.empty(37, 70, dtype=BF, device="cuda")
+    ops.cast_bf16(src.cuda(), dst2)
+    assert torch.equal(dst2.float().cpu(), src)
