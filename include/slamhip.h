@@ -219,6 +219,15 @@ int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long 
                       float beta1, float beta2, float eps, int step, float grad_scale,
                       void* stream);
 
+/* cnn_model.py:167-170 - the other two optimizers the configuration may name:
+ * tf.train.GradientDescentOptimizer (p -= lr g) and tf.train.RMSPropOptimizer
+ * with momentum 0 (ms = decay ms + (1-decay) g^2; p -= lr g / sqrt(ms + eps);
+ * TensorFlow's defaults are decay 0.9, eps 1e-10 and ms starting at one). */
+int slamhip_sgd_step(float* param, const float* grad, long long n, float lr, float grad_scale,
+                     void* stream);
+int slamhip_rmsprop_step(float* param, const float* grad, float* ms, long long n, float lr,
+                         float decay, float eps, float grad_scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -543,6 +543,25 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   p[i] -= lr_t * mi / (sqrtf(vi) + eps);
 }
 
+// tf.train.GradientDescentOptimizer: p -= lr * g
+__global__ void __launch_bounds__(256)
+sgd_kernel(float* __restrict__ p, const float* __restrict__ g, long long n, float lr, float grad_scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] -= lr * (g[i] * grad_scale);
+}
+
+// tf.train.RMSPropOptimizer (momentum 0): ms = decay ms + (1 - decay) g^2; p -= lr g / sqrt(ms + eps)
+__global__ void __launch_bounds__(256)
+rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long long n, float lr,
+               float decay, float eps, float grad_scale) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float gi = g[i] * grad_scale;
+  const float m = decay * ms[i] + (1.0f - decay) * gi * gi;
+  ms[i] = m;
+  p[i] -= lr * gi / sqrtf(m + eps);
+}
+
 static unsigned int blocks_for(long long n, int per = 256) { return (unsigned int)((n + per - 1) / per); }
 
 }  // namespace slamhip
@@ -765,6 +784,24 @@ int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long 
   const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
                      beta1, beta2, eps, grad_scale);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_sgd_step(float* param, const float* grad, long long n, float lr, float grad_scale, void* stream) {
+  SLAMHIP_REQUIRE(param && grad && n >= 0, SLAMHIP_E_ARG, "sgd_step: bad argument");
+  if (n == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(sgd_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, n, lr, grad_scale);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_rmsprop_step(float* param, const float* grad, float* ms, long long n, float lr, float decay, float eps,
+                         float grad_scale, void* stream) {
+  SLAMHIP_REQUIRE(param && grad && ms && n >= 0, SLAMHIP_E_ARG, "rmsprop_step: bad argument");
+  if (n == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(rmsprop_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, ms, n, lr,
+                     decay, eps, grad_scale);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -1,0 +1,366 @@
+"""VGG16-style pose-regression encoder on the MI355X kernels, with the
+reference's class and method names (slam/network/cnn_model.py:14-186).
+
+The reference builds a TensorFlow graph and lets the session run it; here
+`build_graph`, `add_loss` and `add_optimizer` lay out parameters, activations
+and gradients in HBM once, and `apply_gradient_op()` (the object `add_optimizer`
+returns, as in the reference) executes one training step as a fixed sequence of
+kernel launches through the C ABI: forward, loss, hand-derived backward,
+gradient all-reduce when torch.distributed is initialised, optimizer update.
+torch holds the memory and the stream and nothing else; there is no autograd
+and no CPU fallback.
+
+Network (cnn_model.py:31-80): 12 conv3x3 SAME layers in five blocks
+(64,64 | 128,128 | 256,256 | 512x3 | 512x3), each conv -> batch-norm with batch
+statistics -> ReLU, 2x2 max-pool after every block, two ReLU fully connected
+layers and a linear output layer of `output_dim`.
+"""
+import math
+
+import torch
+
+from . import encoder_ops as ops
+from .model_config import get_config_provider
+
+# (name, output channels, max-pool after)   cnn_model.py:37-62
+CONV_LAYERS = (
+    ("conv1_1", 64, False), ("conv1_2", 64, True),
+    ("conv2_1", 128, False), ("conv2_2", 128, True),
+    ("conv3_1", 256, False), ("conv3_2", 256, True),
+    ("conv4_1", 512, False), ("conv4_2", 512, False), ("conv4_3", 512, True),
+    ("conv5_1", 512, False), ("conv5_2", 512, False), ("conv5_3", 512, True),
+)
+OUT_PAD = 64   # the output layer is computed 64 wide (zero columns beyond output_dim)
+
+
+def _round_up(n, m):
+    return (n + m - 1) // m * m
+
+
+class _Optimizer:
+    """Update rule + hyper-parameters of one tf.train optimizer (cnn_model.py:162-170)."""
+
+    def __init__(self, kind, learning_rate):
+        self.kind = kind
+        self.learning_rate = learning_rate   # float or callable(global_step) -> float
+
+
+class VGG16Model:
+
+    def __init__(self, batch_size, rgbd_input_batch, output_dim, normalization_epsilon,
+                 initial_params=None, fc_dim=4096, seed=0):
+        """rgbd_input_batch: float32 GPU tensor [batch, H, W, 4] that the caller refills in
+        place before each step (the reference's placeholder, main/vgg16_rgbd.py:29).
+        initial_params: optional {'conv1_2': {'weights': HWIO array, 'biases': ...}, ...}
+        as the reference reads from its weights file (cnn_model.py:22-23, 129-137);
+        layers without an entry (and conv1_1 always) start from a truncated normal."""
+        if not (rgbd_input_batch.is_cuda and rgbd_input_batch.dtype == torch.float32
+                and rgbd_input_batch.dim() == 4 and rgbd_input_batch.shape[0] == batch_size):
+            raise ValueError("rgbd_input_batch must be a float32 GPU tensor [batch, H, W, C]")
+        _, H, W, _ = rgbd_input_batch.shape
+        if H % 32 or W % 32:
+            raise ValueError("input height and width must be multiples of 32 (five 2x2 pools)")
+        self.network_input = rgbd_input_batch
+        self.output_dim = int(output_dim)
+        if not 0 < self.output_dim <= 8:
+            raise ValueError("output_dim must be in 1..8")
+        self.batch_size = int(batch_size)
+        self.epsilon = float(normalization_epsilon)
+        self.initial_params = initial_params or {}
+        self.fc_dim = int(fc_dim)
+        self.seed = seed
+        self.total_weights = 0
+        self.device = rgbd_input_batch.device
+        self.global_step = 0
+        self._built = False
+
+    # ------------------------------------------------------------------ build
+    def build_graph(self):
+        """Lays out parameters and activations; returns the [batch, output_dim] float32
+        tensor that every forward pass refreshes (cnn_model.py:31-80)."""
+        B, H, W, cin = self.network_input.shape
+        dev = self.device
+        # ---- parameter table: fully connected first (their gradients are complete
+        # first in the backward pass, so their all-reduce starts first)
+        self._spec = []        # (name, kind, shape)
+        feat = (H // 32) * (W // 32) * 512
+        self._spec.append(("out_layer/weights", (self.fc_dim, OUT_PAD)))
+        self._spec.append(("out_layer/bias", (OUT_PAD,)))
+        self._spec.append(("fc7-conv/weights", (self.fc_dim, self.fc_dim)))
+        self._spec.append(("fc7-conv/bias", (self.fc_dim,)))
+        self._spec.append(("fc6-conv/weights", (feat, self.fc_dim)))
+        self._spec.append(("fc6-conv/bias", (self.fc_dim,)))
+        self._fc_end = None
+        c_prev = cin
+        conv_shapes = []
+        for name, cout, _ in CONV_LAYERS:
+            conv_shapes.append((name, c_prev, cout))
+            c_prev = cout
+        for name, ci, co in reversed(conv_shapes):
+            self._spec.append((name + "/weights", (3, 3, ci, co)))
+            self._spec.append((name + "/bn", (2, co)))      # row 0 beta, row 1 scale
+        offs, total = {}, 0
+        for name, shape in self._spec:
+            if name == "conv5_3/weights":
+                self._fc_end = total
+            offs[name] = (total, shape)
+            total += _round_up(math.prod(shape), 64)
+        self._offsets, self._nparams = offs, total
+        self.flat_params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.params = {n: self._view(self.flat_params, n) for n, _ in self._spec}
+        self.grads = {n: self._view(self.flat_grads, n) for n, _ in self._spec}
+        self._init_params(conv_shapes, feat)
+
+        # ---- bfloat16 operand copies of the weights
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        self._w_fwd, self._w_dgrad = {}, {}
+        for name, ci, co in conv_shapes[1:]:
+            self._w_fwd[name] = torch.empty(co, 9 * ci, **bf)
+            self._w_dgrad[name] = torch.empty(ci, 9 * co, **bf)
+        for name in ("fc6-conv", "fc7-conv", "out_layer"):
+            k_in, n_out = self.params[name + "/weights"].shape
+            self._w_fwd[name] = torch.empty(n_out, k_in, **bf)      # [out][in]
+            self._w_dgrad[name] = torch.empty(k_in, n_out, **bf)    # [in][out]
+        self._operands_stale = True
+
+        # ---- activations
+        f32 = dict(dtype=torch.float32, device=dev)
+        self._x = torch.empty(B, H, W, cin, **bf)
+        self._act = []     # per conv layer: dict(z, y, pooled, sums)
+        h, w = H, W
+        for (name, ci, co), (_, _, pool) in zip(conv_shapes, CONV_LAYERS):
+            a = dict(name=name, cin=ci, cout=co, pool=pool,
+                     z=torch.empty(B, h, w, co, **bf), y=torch.empty(B, h, w, co, **bf),
+                     sums=torch.empty(2, co, **f32))
+            if pool:
+                h, w = h // 2, w // 2
+                a["pooled"] = torch.empty(B, h, w, co, **bf)
+            self._act.append(a)
+        self._fc = {}
+        for name, k_in, n_out in (("fc6-conv", feat, self.fc_dim), ("fc7-conv", self.fc_dim, self.fc_dim),
+                                  ("out_layer", self.fc_dim, OUT_PAD)):
+            self._fc[name] = dict(z=torch.empty(B, n_out, **f32), a=torch.empty(B, n_out, **bf),
+                                  dz=torch.empty(B, n_out, **bf), d_in=torch.empty(B, k_in, **f32))
+        self._out_pad = torch.empty(B, OUT_PAD, **f32)
+        self.network_output = torch.empty(B, self.output_dim, **f32)
+        self._scratch = {}
+        self.trace = None      # set to a dict to keep per-layer gradient copies (tests, debugging)
+        self._built = True
+        return self.network_output
+
+    def _view(self, flat, name):
+        off, shape = self._offsets[name]
+        return flat[off:off + math.prod(shape)].view(shape)
+
+    def _init_params(self, conv_shapes, feat):
+        """truncated normal (stddev 5e-2, cut at two stddev) unless initial values are given
+        (cnn_model.py:129-137); batch-norm scale ones, beta zeros (cnn_model.py:105-106)."""
+        g = torch.Generator().manual_seed(self.seed)
+
+        def trunc(shape):
+            t = torch.empty(shape)
+            torch.nn.init.trunc_normal_(t, mean=0.0, std=5e-2, a=-0.1, b=0.1, generator=g)
+            return t
+
+        def initial(scope, key, shape, allow=True):
+            init = self.initial_params.get(scope) if allow else None
+            if init is not None and key in init:
+                t = torch.as_tensor(init[key], dtype=torch.float32).reshape(shape)
+                return t
+            return trunc(shape)
+
+        for i, (name, ci, co) in enumerate(conv_shapes):
+            self.total_weights += 9 * ci * co
+            self.params[name + "/weights"].copy_(initial(name, "weights", (3, 3, ci, co), allow=i > 0))
+            self.params[name + "/bn"][0].zero_()
+            self.params[name + "/bn"][1].fill_(1.0)
+        for name, k_in, n_out in (("fc6-conv", feat, self.fc_dim), ("fc7-conv", self.fc_dim, self.fc_dim)):
+            self.params[name + "/weights"].copy_(initial(name, "weights", (k_in, n_out)))
+            self.params[name + "/bias"].copy_(initial(name, "biases", (n_out,)))
+        D = self.output_dim
+        self.params["out_layer/weights"][:, :D].copy_(trunc((self.fc_dim, D)))
+        self.params["out_layer/bias"][:D].copy_(trunc((D,)))
+
+    # the reference's builder methods, kept for callers that extend the network
+    def add_conv_layer(self, scope_name, layer_input, filter_size, input_channels, output_channels,
+                       padding='SAME', should_init_wb=True):
+        raise NotImplementedError("layers are fixed by build_graph(); see CONV_LAYERS")
+
+    def add_fc_layer(self, scope_name, layer_input, input_dim, out_dim):
+        raise NotImplementedError("layers are fixed by build_graph()")
+
+    # ---------------------------------------------------------------- forward
+    def _refresh_operands(self):
+        for a in self._act[1:]:
+            n = a["name"]
+            ops.conv_weight_layouts(self.params[n + "/weights"], self._w_fwd[n], self._w_dgrad[n])
+        for n in ("fc6-conv", "fc7-conv", "out_layer"):
+            w = self.params[n + "/weights"]
+            ops.transpose_cast(w, self._w_fwd[n])
+            ops.cast_bf16(w, self._w_dgrad[n])
+        self._operands_stale = False
+
+    def forward(self):
+        """network_input -> network_output (batch statistics in the normalisation,
+        as the reference does in training and inference alike)."""
+        assert self._built, "call build_graph() first"
+        if self._operands_stale:
+            self._refresh_operands()
+        ops.cast_bf16(self.network_input, self._x)
+        h = self._x
+        for i, a in enumerate(self._act):
+            n = a["name"]
+            if i == 0:
+                ops.conv3x3_small(h, self.params[n + "/weights"], a["z"])
+            else:
+                ops.conv3x3(h, self._w_fwd[n], out_bf16=a["z"])
+            bn = self.params[n + "/bn"]
+            ops.channel_stats(a["z"], a["sums"])
+            ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
+            h = a["y"]
+            if a["pool"]:
+                ops.maxpool2(a["y"], a["pooled"])
+                h = a["pooled"]
+        B = self.batch_size
+        h = h.view(B, -1)
+        for n in ("fc6-conv", "fc7-conv"):
+            f = self._fc[n]
+            ops.gemm_nt(h, self._w_fwd[n], out_f32=f["z"])
+            ops.bias_act(f["z"], self.params[n + "/bias"], y_bf16=f["a"], relu=True)
+            h = f["a"]
+        f = self._fc["out_layer"]
+        ops.gemm_nt(h, self._w_fwd["out_layer"], out_f32=f["z"])
+        ops.bias_act(f["z"], self.params["out_layer/bias"], y_f32=self._out_pad, relu=False)
+        self.network_output.copy_(self._out_pad[:, :self.output_dim])
+        return self.network_output
+
+    # ------------------------------------------------------------------- loss
+    def add_loss(self, loss_weight, ground_truth):
+        """loss = l2_loss((network_output - ground_truth) . loss_weight) (cnn_model.py:139-144).
+        Both arguments are float32 GPU tensors the caller refills in place."""
+        self._loss_weight, self._ground_truth = loss_weight, ground_truth
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._d_out = torch.zeros(self.batch_size, self.output_dim, dtype=torch.float32, device=self.device)
+        self._d_out_pad = torch.zeros(self.batch_size, OUT_PAD, dtype=torch.float32, device=self.device)
+        return self.loss
+
+    def compute_loss(self, with_gradient=True):
+        ops.l2loss(self.network_output, self._ground_truth, self._loss_weight, self.loss,
+                   self._d_out if with_gradient else None)
+        return self.loss
+
+    # --------------------------------------------------------------- backward
+    def _buf(self, key, like):
+        t = self._scratch.get(key)
+        if t is None or t.shape != like.shape:
+            t = self._scratch[key] = torch.empty_like(like)
+        return t
+
+    def backward(self, on_fc_done=None):
+        """Gradients of `loss` with respect to every parameter, into `grads` (views of
+        `flat_grads`).  on_fc_done() is called once the fully connected gradients are
+        complete (the data-parallel step starts their all-reduce there)."""
+        self._d_out_pad[:, :self.output_dim].copy_(self._d_out)
+        d = self._d_out_pad
+        order = ("out_layer", "fc7-conv", "fc6-conv")
+        last_conv = self._act[-1]
+        feat_in = (last_conv["pooled"] if last_conv["pool"] else last_conv["y"]).view(self.batch_size, -1)
+        inputs = {"out_layer": self._fc["fc7-conv"]["a"], "fc7-conv": self._fc["fc6-conv"]["a"], "fc6-conv": feat_in}
+        d_feat = self._buf("d_feat", feat_in)
+        for n in order:
+            f = self._fc[n]
+            relu = n != "out_layer"
+            ops.bias_act_bwd(d, f["a"] if relu else None, f["dz"], self.grads[n + "/bias"], relu=relu)
+            ops.wgrad(inputs[n], f["dz"], self.grads[n + "/weights"])
+            if n == "fc6-conv":
+                ops.gemm_nt(f["dz"], self._w_dgrad[n], out_bf16=d_feat)
+            else:
+                ops.gemm_nt(f["dz"], self._w_dgrad[n], out_f32=f["d_in"])
+                d = f["d_in"]
+        if on_fc_done is not None:
+            on_fc_done()
+        g = d_feat.view_as(last_conv["pooled"] if last_conv["pool"] else last_conv["y"])
+        if self.trace is not None:
+            self.trace["d_feat"] = g.clone()
+        for i in range(len(self._act) - 1, -1, -1):
+            a = self._act[i]
+            n = a["name"]
+            g_out = g.clone() if self.trace is not None else None
+            if a["pool"]:
+                dy = self._buf(("dy", a["y"].shape), a["y"])
+                ops.maxpool2_bwd(a["y"], a["pooled"], g, dy)
+                g = dy
+            dz = self._buf(("dz", a["z"].shape), a["z"])
+            bn = self.params[n + "/bn"]
+            ops.bn_relu_bwd(g, a["y"], a["z"], a["sums"], bn[1], self.grads[n + "/bn"], dz, self.epsilon)
+            if i == 0:
+                ops.conv3x3_small_wgrad(self._x, dz, self.grads[n + "/weights"])
+            else:
+                prev = self._act[i - 1]
+                h_in = prev["pooled"] if prev["pool"] else prev["y"]
+                ops.wgrad(h_in, dz, self.grads[n + "/weights"])
+                d_in = self._buf(("din", h_in.shape), h_in)
+                ops.conv3x3(dz, self._w_dgrad[n], out_bf16=d_in, flip=True)
+                g = d_in
+            if self.trace is not None:
+                self.trace[n] = dict(g_out=g_out, dz=dz.clone(), d_in=g.clone() if i else None)
+
+    # -------------------------------------------------------------- optimizer
+    def add_optimizer(self):
+        """Adam (or the optimizer the configuration names) on a learning rate of
+        0.01 * 0.1^(global_step // 5) (cnn_model.py:146-160).  Returns the callable that
+        runs one training step and gives back the loss tensor."""
+        self.global_step = 0
+        learning_rate = lambda step: 0.01 * 0.1 ** (step // 5)   # exponential_decay, staircase
+        self._optimizer = self.get_optimizer(learning_rate)
+        if self._optimizer.kind == 'AdamOptimizer':
+            self._adam_m = torch.zeros_like(self.flat_params)
+            self._adam_v = torch.zeros_like(self.flat_params)
+        elif self._optimizer.kind == 'RMSPropOptimizer':
+            self._rms = torch.ones_like(self.flat_params)    # TensorFlow starts the mean square at one
+        self.apply_gradient_op = self.train_step
+        return self.apply_gradient_op
+
+    def get_optimizer(self, learning_rate):
+        opt = get_config_provider().optimizer()
+        if opt not in ('AdamOptimizer', 'GradientDescentOptimizer', 'RMSPropOptimizer'):
+            raise ValueError("unknown optimizer %r" % (opt,))
+        return _Optimizer(opt, learning_rate)
+
+    def _apply_gradients(self, grad_scale):
+        o = self._optimizer
+        lr = o.learning_rate(self.global_step) if callable(o.learning_rate) else o.learning_rate
+        if o.kind == 'AdamOptimizer':
+            ops.adam_step(self.flat_params, self.flat_grads, self._adam_m, self._adam_v, lr,
+                          step=self.global_step + 1, grad_scale=grad_scale)
+        elif o.kind == 'GradientDescentOptimizer':
+            ops.sgd_step(self.flat_params, self.flat_grads, lr, grad_scale=grad_scale)
+        else:
+            ops.rmsprop_step(self.flat_params, self.flat_grads, self._rms, lr, grad_scale=grad_scale)
+        self.global_step += 1
+        self._operands_stale = True
+
+    def train_step(self):
+        """forward, loss, backward, gradient mean over the data-parallel ranks, update."""
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.forward()
+        self.compute_loss(with_gradient=True)
+        pending = []
+        if world > 1:
+            fc_bucket = self.flat_grads[:self._fc_end]
+            self.backward(on_fc_done=lambda: pending.append(dist.all_reduce(fc_bucket, async_op=True)))
+            pending.append(dist.all_reduce(self.flat_grads[self._fc_end:], async_op=True))
+            for w in pending:
+                w.wait()
+        else:
+            self.backward()
+        self._apply_gradients(1.0 / world)
+        return self.loss
+
+    def start_training(self, max_steps):
+        """cnn_model.py:175-181."""
+        for _ in range(max_steps):
+            self.train_step()
+        return self.loss

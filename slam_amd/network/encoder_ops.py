@@ -176,3 +176,16 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gra
         assert _chk(t, F32, "adam tensor").numel() == n
     _call("slamhip_adam_step", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, float(lr), float(beta1),
           float(beta2), float(eps), int(step), float(grad_scale))
+
+
+def sgd_step(param, grad, lr, grad_scale=1.0):
+    n = _chk(param, F32, "param").numel()
+    assert _chk(grad, F32, "grad").numel() == n
+    _call("slamhip_sgd_step", capi.ptr(param), capi.ptr(grad), n, float(lr), float(grad_scale))
+
+
+def rmsprop_step(param, grad, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0):
+    n = _chk(param, F32, "param").numel()
+    assert _chk(grad, F32, "grad").numel() == n and _chk(ms, F32, "ms").numel() == n
+    _call("slamhip_rmsprop_step", capi.ptr(param), capi.ptr(grad), capi.ptr(ms), n, float(lr), float(decay),
+          float(eps), float(grad_scale))
