@@ -28,40 +28,63 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_PITCH = 72;   // 64 bf16 of payload + 8 of padding per row (144 B)
 
+// Zeroing by mask keeps the value in registers (a select between two 16-byte values can
+// be lowered to an indexed read of a stack copy).
+__device__ __forceinline__ uint4 and4(uint4 v, uint32_t keep) {
+  return make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+}
+
 // ---------------------------------------------------------------------------
 // implicit GEMM:  out[m][n] = sum_{tap,c} A[pixel(m) + tap][c] * Bw[n][tap*C + c]
 // TAPS = 9: 3x3 SAME convolution over NHWC A (flip = 1 walks the taps backwards:
 //           the data gradient with Bw = the flipped, in/out-swapped filter)
 // TAPS = 1: plain NT GEMM, A [M][C], Bw [N][C]
 // ---------------------------------------------------------------------------
-template <int TAPS, int BN>
+template <int TAPS, int BN, bool WRITE_BF16, bool WRITE_F32>
 __global__ void __launch_bounds__(256)
 igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
-                  float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip) {
+                  float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip, int n_tiles,
+                  int total_tiles) {
   constexpr int BM = 128;
   constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
-  constexpr int BROWS_PER_PASS = 256 / 8;     // B loader: 8 threads (16 B each) cover one 64-element row
+  constexpr int NB = BN / 32;                 // B loader passes: 8 threads (16 B each) cover one 64-element row
   __shared__ __attribute__((aligned(16))) bf16 As[BM * LDS_PITCH];
   __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LDS_PITCH];
 
+  // Workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of
+  // tiles so the n-tiles of a pixel tile and its neighbours (tap halos) share an L2.
+  const int per_xcd = (total_tiles + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_tiles) return;
+  const int m0 = (work / n_tiles) * BM, n0 = (work % n_tiles) * BN;
+
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int Ktot = TAPS * C;
 
-  // A loader: thread -> row (pixel) tid>>1, 64-byte half tid&1
+  // A loader: thread -> row (pixel) tid>>1, 64-byte half tid&1.  Rows beyond M and taps
+  // outside the image load a valid dummy address and are zeroed on the way into LDS.
   const int a_row = tid >> 1, a_half = tid & 1;
-  const int pm = m0 + a_row;
-  int pb = 0, py = 0, px = 0;
+  const bool row_ok = m0 + a_row < M;
+  const int pm = row_ok ? m0 + a_row : M - 1;
+  int py = 0, px = 0;
   if (TAPS == 9) {
     const int hw = H * W;
-    pb = pm / hw;
-    const int rem = pm - pb * hw;
+    const int rem = pm % hw;
     py = rem / W;
     px = rem - py * W;
   }
+  const bf16* a_base = A + (long long)pm * C + a_half * 32;
   // B loader: row tid>>3 (+32 per pass), 16-byte chunk tid&7
   const int b_row = tid >> 3, b_chunk = tid & 7;
+  const bf16* b_base[NB];
+  bool b_ok[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int n = n0 + b_row + i * 32;
+    b_ok[i] = n < N;
+    b_base[i] = Bw + (long long)(b_ok[i] ? n : N - 1) * Ktot + b_chunk * 8;
+  }
 
   f32x16 acc[2][NT];
 #pragma unroll
@@ -71,41 +94,42 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   const int ksteps = TAPS * (C / 64);
-  uint4 ra[4], rb[BN / BROWS_PER_PASS];
+  uint4 ra0, ra1, ra2, ra3, rb[NB];
+  bool a_ok;
+  int tap = 0, c0 = 0;   // position of the loads in flight
 
-  auto issue_loads = [&](int s) {
-    const int tap = s / (C / 64), c0 = (s - tap * (C / 64)) * 64;
-    const bf16* src = nullptr;
-    if (TAPS == 9) {
-      const int t = flip ? 8 - tap : tap;
-      const int yy = py + t / 3 - 1, xx = px + t % 3 - 1;
-      if (pm < M && yy >= 0 && yy < H && xx >= 0 && xx < W)
-        src = A + ((long long)(pb * H + yy) * W + xx) * C + c0 + a_half * 32;
-    } else if (pm < M) {
-      src = A + (long long)pm * C + c0 + a_half * 32;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = src ? reinterpret_cast<const uint4*>(src)[i] : zero4;
-#pragma unroll
-    for (int i = 0; i < BN / BROWS_PER_PASS; ++i) {
-      const int n = n0 + b_row + i * BROWS_PER_PASS;
-      rb[i] = (n < N) ? *reinterpret_cast<const uint4*>(Bw + (long long)n * Ktot + tap * C + c0 + b_chunk * 8) : zero4;
-    }
-  };
+#define SLAMHIP_IGEMM_ISSUE()                                                                   \
+  {                                                                                             \
+    long long delta = c0;                                                                       \
+    a_ok = row_ok;                                                                              \
+    if (TAPS == 9) {                                                                            \
+      const int t = flip ? 8 - tap : tap;                                                       \
+      const int dy = t / 3 - 1, dx = t - (t / 3) * 3 - 1;                                       \
+      a_ok = row_ok && (unsigned)(py + dy) < (unsigned)H && (unsigned)(px + dx) < (unsigned)W;  \
+      if (a_ok) delta += (long long)(dy * W + dx) * C;                                          \
+    }                                                                                           \
+    const uint4* src = reinterpret_cast<const uint4*>(a_base + delta);                          \
+    ra0 = src[0]; ra1 = src[1]; ra2 = src[2]; ra3 = src[3];                                     \
+    _Pragma("unroll") for (int i = 0; i < NB; ++i)                                              \
+      rb[i] = *reinterpret_cast<const uint4*>(b_base[i] + tap * C + c0);                        \
+    c0 += 64;                                                                                   \
+    if (c0 == C) { c0 = 0; ++tap; }                                                             \
+  }
 
-  issue_loads(0);
+  SLAMHIP_IGEMM_ISSUE();
   for (int s = 0; s < ksteps; ++s) {
     __syncthreads();   // the previous step's fragments have been read
+    {
+      uint4* dst = reinterpret_cast<uint4*>(&As[a_row * LDS_PITCH + a_half * 32]);
+      const uint32_t keep = a_ok ? 0xffffffffu : 0u;
+      dst[0] = and4(ra0, keep); dst[1] = and4(ra1, keep); dst[2] = and4(ra2, keep); dst[3] = and4(ra3, keep);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(&As[a_row * LDS_PITCH + a_half * 32 + i * 8]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BN / BROWS_PER_PASS; ++i)
-      *reinterpret_cast<uint4*>(&Bs[(b_row + i * BROWS_PER_PASS) * LDS_PITCH + b_chunk * 8]) = rb[i];
+    for (int i = 0; i < NB; ++i)
+      *reinterpret_cast<uint4*>(&Bs[(b_row + i * 32) * LDS_PITCH + b_chunk * 8]) = and4(rb[i], b_ok[i] ? 0xffffffffu : 0u);
     __syncthreads();
-    if (s + 1 < ksteps) issue_loads(s + 1);   // in flight while the matrix cores work
+    if (s + 1 < ksteps) SLAMHIP_IGEMM_ISSUE();   // in flight while the matrix cores work
 #pragma unroll
     for (int kk = 0; kk < 64; kk += 16) {
       bf16x8 af[2], bfr[NT];
@@ -121,6 +145,7 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
         for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
+#undef SLAMHIP_IGEMM_ISSUE
 
   // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -133,8 +158,8 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
         const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
         if (m < M && n < N) {
           const float v = acc[i][j][r];
-          if (out_bf16) out_bf16[(long long)m * N + n] = (bf16)v;
-          if (out_f32) out_f32[(long long)m * N + n] = v;
+          if (WRITE_BF16) out_bf16[(long long)m * N + n] = (bf16)v;
+          if (WRITE_F32) out_f32[(long long)m * N + n] = v;
         }
       }
 }
@@ -174,45 +199,48 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
   const int chunk = (P + splitk - 1) / splitk;
   const int p_begin = slice * chunk, p_end = min(P, p_begin + chunk);
 
-  // loader: thread -> pixel row tid>>2 of the 64-pixel step, 32-byte quarter tid&3
+  // loader: thread -> pixel row tid>>2 of the 64-pixel step, 32-byte quarter tid&3.  Rows past
+  // the slice and taps outside the image read a valid dummy address and are zeroed by mask.
   const int l_row = tid >> 2, l_q = tid & 3;
-  const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  uint4 rx[2], ry[2];
+  uint4 rx0, rx1, ry0, ry1;
+  uint32_t keep_x = 0u, keep_y = 0u;
+  const int hw = H * W;
+  const bf16* x_col = X + ci0 + l_q * 16;
+  const bf16* y_col = dY + co0 + l_q * 16;
 
-  auto issue_loads = [&](int p0) {
-    const int p = p0 + l_row;
-    const bf16* xs = nullptr;
-    const bf16* ys = nullptr;
-    if (p < p_end) {
-      ys = dY + (long long)p * Cout + co0 + l_q * 16;
-      if (TAPS == 9) {
-        const int hw = H * W, b = p / hw, rem = p - b * hw, y = rem / W, x = rem - y * W;
-        const int yy = y + dy, xx = x + dx;
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) xs = X + ((long long)(b * H + yy) * W + xx) * Cin + ci0 + l_q * 16;
-      } else {
-        xs = X + (long long)p * Cin + ci0 + l_q * 16;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      rx[i] = xs ? reinterpret_cast<const uint4*>(xs)[i] : zero4;
-      ry[i] = ys ? reinterpret_cast<const uint4*>(ys)[i] : zero4;
-    }
-  };
+#define SLAMHIP_WGRAD_ISSUE(p0)                                                                     \
+  {                                                                                                 \
+    const int p = (p0) + l_row;                                                                     \
+    const bool in_slice = p < p_end;                                                                \
+    const int pc = in_slice ? p : p_end - 1;                                                        \
+    long long xo = (long long)pc * Cin;                                                             \
+    bool x_ok = in_slice;                                                                           \
+    if (TAPS == 9) {                                                                                \
+      const int rem = pc % hw, y = rem / W, x = rem - y * W;                                        \
+      x_ok = in_slice && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;      \
+      if (x_ok) xo += (long long)(dy * W + dx) * Cin;                                               \
+    }                                                                                               \
+    const uint4* xs = reinterpret_cast<const uint4*>(x_col + xo);                                   \
+    const uint4* ys = reinterpret_cast<const uint4*>(y_col + (long long)pc * Cout);                 \
+    rx0 = xs[0]; rx1 = xs[1]; ry0 = ys[0]; ry1 = ys[1];                                             \
+    keep_x = x_ok ? 0xffffffffu : 0u;                                                               \
+    keep_y = in_slice ? 0xffffffffu : 0u;                                                           \
+  }
 
-  if (p_begin < p_end) issue_loads(p_begin);
+  if (p_begin < p_end) SLAMHIP_WGRAD_ISSUE(p_begin);
   for (int p0 = p_begin; p0 < p_end; p0 += 64) {
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(&Xs[l_row * LDS_PITCH + l_q * 16 + i * 8]) = rx[i];
-      *reinterpret_cast<uint4*>(&Ys[l_row * LDS_PITCH + l_q * 16 + i * 8]) = ry[i];
+    {
+      uint4* xd = reinterpret_cast<uint4*>(&Xs[l_row * LDS_PITCH + l_q * 16]);
+      uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * LDS_PITCH + l_q * 16]);
+      xd[0] = and4(rx0, keep_x); xd[1] = and4(rx1, keep_x);
+      yd[0] = and4(ry0, keep_y); yd[1] = and4(ry1, keep_y);
     }
     __syncthreads();
-    if (p0 + 64 < p_end) issue_loads(p0 + 64);
+    if (p0 + 64 < p_end) SLAMHIP_WGRAD_ISSUE(p0 + 64);
 #pragma unroll
     for (int kk = 0; kk < 64; kk += 16) {
       const bf16x8 af = tr_frag(Xs, kk, wm * 32, lane);   // A[m = ci][k = pixel]
@@ -220,6 +248,7 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
       acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
     }
   }
+#undef SLAMHIP_WGRAD_ISSUE
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -272,29 +301,117 @@ conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ 
   atomicAdd(&dW[(t * Cin + ci) * Cout + co], acc);
 }
 
+// Specialisation for the network's actual first layer (4 input channels, 64 filters):
+// lane = output channel, a wave walks a run of pixels.  The 36 inputs of a pixel are the
+// same for all lanes, so they come through the scalar cache; each lane keeps its filter
+// column (forward) or its 36 partial sums (filter gradient) in registers.
+__device__ __forceinline__ void unpack4(uint2 v, float* f) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+
+template <bool WGRAD>
+__global__ void __launch_bounds__(256)
+conv3x3_c4_k64_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, const bf16* __restrict__ dY,
+                      bf16* __restrict__ out, float* __restrict__ dW, int P, int H, int W, int px_per_wave) {
+  const int co = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+  const long long p0l = (long long)wave * px_per_wave;
+  if (p0l >= P) return;
+  const int p0 = (int)p0l, p1 = min(P, p0 + px_per_wave);
+  float w[36];
+#pragma unroll
+  for (int k = 0; k < 36; ++k) w[k] = WGRAD ? 0.0f : Wt[k * 64 + co];
+  int rem = p0 % (H * W);
+  int y = rem / W, x = rem - y * W;
+  const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
+  for (int p = p0; p < p1; ++p) {
+    float acc = 0.0f, g = 0.0f;
+    if (WGRAD) g = (float)dY[(long long)p * 64 + co];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;   // wave-uniform
+      uint2 v = make_uint2(0u, 0u);
+      if (ok) v = Xp[p + dy * W + dx];
+      float f[4];
+      unpack4(v, f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (WGRAD) w[t * 4 + c] = __builtin_fmaf(f[c], g, w[t * 4 + c]);
+        else acc = __builtin_fmaf(f[c], w[t * 4 + c], acc);
+      }
+    }
+    if (!WGRAD) out[(long long)p * 64 + co] = (bf16)acc;
+    if (++x == W) { x = 0; if (++y == H) y = 0; }
+  }
+  if (WGRAD) {
+#pragma unroll
+    for (int k = 0; k < 36; ++k) atomicAdd(&dW[k * 64 + co], w[k]);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // per-channel statistics and batch-norm + ReLU (cnn_model.py:104-113; batch
 // statistics always, biased variance)
 // ---------------------------------------------------------------------------
-// sums[c] += sum_p z[p][c], sums[C + c] += sum_p z[p][c]^2.  Thread = channel pair
-// column, block walks a slice of rows; C is a multiple of 64.
+// Column reductions over the P rows of an [P][C] bfloat16 matrix, 16 bytes (8 channels) per
+// thread per row: a block is (C/8 column groups) x (256 / (C/8) row lanes), rows strided over
+// the grid; partial sums meet in LDS and leave as 2C float atomics per block.
+//   BWD = false: out[c] += sum z,   out[C + c] += sum z^2                      (statistics)
+//   BWD = true : out[c] += sum g,   out[C + c] += sum g * xhat,  g = dy * (y > 0)
+template <bool BWD>
 __global__ void __launch_bounds__(256)
-channel_stats_kernel(const bf16* __restrict__ z, float* __restrict__ sums, int P, int C) {
-  const int cols = C / 2;                       // channel pairs
-  const int per_block = 256 / min(cols, 256);   // row lanes per block when C < 512
-  const int col = threadIdx.x % cols, sub = threadIdx.x / cols;
-  if (sub >= per_block) return;
-  const int slices = gridDim.x * per_block, slice = blockIdx.x * per_block + sub;
-  const int chunk = (P + slices - 1) / slices, p0 = slice * chunk, p1 = min(P, p0 + chunk);
-  for (int cb = col; cb < cols; cb += 256) {
-    float s0 = 0.f, s1 = 0.f, q0 = 0.f, q1 = 0.f;
-    for (int p = p0; p < p1; ++p) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(z + (long long)p * C + 2 * cb);
-      const float a = __uint_as_float(v << 16), b = __uint_as_float(v & 0xffff0000u);
-      s0 += a; s1 += b; q0 = __builtin_fmaf(a, a, q0); q1 = __builtin_fmaf(b, b, q1);
+channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, const bf16* __restrict__ z,
+                      const float* __restrict__ sums, float* __restrict__ out, int P, int C, float inv_count,
+                      float eps) {
+  __shared__ float part[256 * 17];
+  const int groups = C >> 3;                      // <= 256 (checked on the host)
+  const int rlanes = 256 / groups;
+  const int gcol = threadIdx.x % groups, rlane = threadIdx.x / groups;
+  float s0[8], s1[8], mean[8], rstd[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 0.f; }
+  if (rlane < rlanes) {
+    if (BWD) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int c = gcol * 8 + j;
+        mean[j] = sums[c] * inv_count;
+        rstd[j] = rsqrtf(fmaxf(sums[C + c] * inv_count - mean[j] * mean[j], 0.0f) + eps);
+      }
     }
-    atomicAdd(&sums[2 * cb], s0); atomicAdd(&sums[2 * cb + 1], s1);
-    atomicAdd(&sums[C + 2 * cb], q0); atomicAdd(&sums[C + 2 * cb + 1], q1);
+    const int stride = gridDim.x * rlanes;
+    for (int p = blockIdx.x * rlanes + rlane; p < P; p += stride) {
+      const long long o = ((long long)p * C >> 3) + gcol;
+      const bf16x8 va = reinterpret_cast<const bf16x8*>(a)[o];
+      if (BWD) {
+        const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[o], vz = reinterpret_cast<const bf16x8*>(z)[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float g = ((float)vy[j] > 0.0f) ? (float)va[j] : 0.0f;
+          s0[j] += g;
+          s1[j] = __builtin_fmaf(g, ((float)vz[j] - mean[j]) * rstd[j], s1[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = (float)va[j];
+          s0[j] += v;
+          s1[j] = __builtin_fmaf(v, v, s1[j]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { part[threadIdx.x * 17 + j] = s0[j]; part[threadIdx.x * 17 + 8 + j] = s1[j]; }
+  __syncthreads();
+  // thread t < 16 * groups: column group t / 16, quantity t % 16, summed over the row lanes
+  for (int t = threadIdx.x; t < 16 * groups; t += 256) {
+    const int gc = t >> 4, k = t & 15;
+    float acc = 0.f;
+    for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
+    atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
   }
 }
 
@@ -316,32 +433,6 @@ bn_relu_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ sums, c
     o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[j] - mean, r, beta[c0 + j]), 0.0f);
   }
   reinterpret_cast<bf16x8*>(y)[i] = o;
-}
-
-// backward reductions: red[c] += sum dyr, red[C + c] += sum dyr * xhat, dyr = dy * (y > 0)
-__global__ void __launch_bounds__(256)
-bn_relu_bwd_reduce_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ z,
-                          const float* __restrict__ sums, float* __restrict__ red, int P, int C, float inv_count,
-                          float eps) {
-  const int cols = min(C, 256), per_block = 256 / cols;
-  const int col = threadIdx.x % cols, sub = threadIdx.x / cols;
-  if (sub >= per_block) return;
-  const int slices = gridDim.x * per_block, slice = blockIdx.x * per_block + sub;
-  const int chunk = (P + slices - 1) / slices, p0 = slice * chunk, p1 = min(P, p0 + chunk);
-  for (int c = col; c < C; c += 256) {
-    const float mean = sums[c] * inv_count;
-    const float var = fmaxf(sums[C + c] * inv_count - mean * mean, 0.0f);
-    const float rstd = rsqrtf(var + eps);
-    float s = 0.f, sx = 0.f;
-    for (int p = p0; p < p1; ++p) {
-      const long long o = (long long)p * C + c;
-      const float g = ((float)y[o] > 0.0f) ? (float)dy[o] : 0.0f;
-      s += g;
-      sx = __builtin_fmaf(g, ((float)z[o] - mean) * rstd, sx);
-    }
-    atomicAdd(&red[c], s);
-    atomicAdd(&red[C + c], sx);
-  }
 }
 
 // dz = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat))
@@ -564,6 +655,28 @@ rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
 
 static unsigned int blocks_for(long long n, int per = 256) { return (unsigned int)((n + per - 1) / per); }
 
+
+// rows are strided over the grid: enough blocks to fill the chip, at least ~8 rows per row lane
+static unsigned int reduce_grid(long long P, int C) {
+  const int rlanes = 256 / (C / 8);
+  long long g = (P + 8LL * rlanes - 1) / (8LL * rlanes);
+  return (unsigned int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+template <int TAPS, int BN>
+static void launch_igemm(const void* a, const void* b, void* out_bf16, float* out_f32, long long M, int N, int C,
+                         int H, int W, int flip, hipStream_t s) {
+  const int m_tiles = (int)((M + 127) / 128), n_tiles = (N + BN - 1) / BN, total = m_tiles * n_tiles;
+  const dim3 grid((total + 7) / 8 * 8), block(256);
+#define SLAMHIP_IGEMM_GO(WB, WF)                                                                                 \
+  hipLaunchKernelGGL((igemm_bf16_kernel<TAPS, BN, WB, WF>), grid, block, 0, s, (const bf16*)a, (const bf16*)b, \
+                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total)
+  if (out_bf16 && out_f32) SLAMHIP_IGEMM_GO(true, true);
+  else if (out_bf16) SLAMHIP_IGEMM_GO(true, false);
+  else SLAMHIP_IGEMM_GO(false, true);
+#undef SLAMHIP_IGEMM_GO
+}
+
 }  // namespace slamhip
 
 using namespace slamhip;
@@ -579,12 +692,8 @@ int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16
   const long long M = (long long)B * H * W;
   SLAMHIP_REQUIRE(M <= 0x7fffffffLL, SLAMHIP_E_SIZE, "conv3x3_igemm: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0)
-    hipLaunchKernelGGL((igemm_bf16_kernel<9, 128>), dim3((unsigned)((M + 127) / 128), N / 128), dim3(256), 0, s,
-                       (const bf16*)act, (const bf16*)w_nk, (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip);
-  else
-    hipLaunchKernelGGL((igemm_bf16_kernel<9, 64>), dim3((unsigned)((M + 127) / 128), (N + 63) / 64), dim3(256), 0, s,
-                       (const bf16*)act, (const bf16*)w_nk, (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip);
+  if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
+  else launch_igemm<9, 64>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -596,12 +705,8 @@ int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, flo
   SLAMHIP_REQUIRE(a_mk && b_nk && (out_bf16 || out_f32), SLAMHIP_E_ARG, "gemm_nt: null pointer");
   SLAMHIP_REQUIRE(K % 64 == 0, SLAMHIP_E_SIZE, "gemm_nt: K (%d) must be a multiple of 64", K);
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0)
-    hipLaunchKernelGGL((igemm_bf16_kernel<1, 128>), dim3((M + 127) / 128, N / 128), dim3(256), 0, s, (const bf16*)a_mk,
-                       (const bf16*)b_nk, (bf16*)out_bf16, out_f32, M, N, K, 1, 1, 0);
-  else
-    hipLaunchKernelGGL((igemm_bf16_kernel<1, 64>), dim3((M + 127) / 128, (N + 63) / 64), dim3(256), 0, s,
-                       (const bf16*)a_mk, (const bf16*)b_nk, (bf16*)out_bf16, out_f32, M, N, K, 1, 1, 0);
+  if (N % 128 == 0) launch_igemm<1, 128>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s);
+  else launch_igemm<1, 64>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -640,8 +745,16 @@ int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16
                   "conv3x3_small_fwd: bad argument");
   const long long total = (long long)B * H * W * Cout;
   if (total == 0) return SLAMHIP_OK;
-  hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)x, w_hwio, (bf16*)out_bf16, B * H * W, H, W, Cin, Cout);
+  const int P = B * H * W;
+  if (Cin == 4 && Cout == 64) {
+    const int px_per_wave = 64, waves = (P + px_per_wave - 1) / px_per_wave;
+    hipLaunchKernelGGL(conv3x3_c4_k64_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, w_hwio, (const bf16*)nullptr, (bf16*)out_bf16, (float*)nullptr, P, H, W,
+                       px_per_wave);
+  } else {
+    hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, w_hwio, (bf16*)out_bf16, P, H, W, Cin, Cout);
+  }
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -653,8 +766,17 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
   hipStream_t s = (hipStream_t)stream;
   SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
   if (B == 0) return SLAMHIP_OK;
-  hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
-                     dw, B * H * W, H, W, Cin, Cout);
+  const int P = B * H * W;
+  if (Cin == 4 && Cout == 64) {
+    int px_per_wave = (P + 8191) / 8192;          // about 8192 waves, each ending in 36 atomics per lane
+    if (px_per_wave < 16) px_per_wave = 16;
+    const int waves = (P + px_per_wave - 1) / px_per_wave;
+    hipLaunchKernelGGL(conv3x3_c4_k64_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, (const bf16*)x,
+                       (const float*)nullptr, (const bf16*)dy, (bf16*)nullptr, dw, P, H, W, px_per_wave);
+  } else {
+    hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x,
+                       (const bf16*)dy, dw, P, H, W, Cin, Cout);
+  }
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -665,8 +787,9 @@ int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void
   SLAMHIP_HIP(hipMemsetAsync(sums2c, 0, sizeof(float) * 2 * (size_t)C, s));
   if (P == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
-  const unsigned grid = (unsigned)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
-  hipLaunchKernelGGL(channel_stats_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)z, sums2c, (int)P, C);
+  SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "channel_stats: more than 2048 channels");
+  hipLaunchKernelGGL(channel_reduce_kernel<false>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)z,
+                     (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr, sums2c, (int)P, C, 0.0f, 0.0f);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -689,9 +812,9 @@ int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const floa
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_bwd: too many rows");
   hipStream_t s = (hipStream_t)stream;
   SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
-  const unsigned grid = (unsigned)((P + 255) / 256 < 1024 ? (P + 255) / 256 : 1024);
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
-                     (const bf16*)z, sums2c, red2c, (int)P, C, 1.0f / (float)P, eps);
+  SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
+  hipLaunchKernelGGL(channel_reduce_kernel<true>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
+                     (const bf16*)y, (const bf16*)z, sums2c, red2c, (int)P, C, 1.0f / (float)P, eps);
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)y, (const bf16*)z, sums2c, red2c, gamma, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
