@@ -169,15 +169,19 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 // (TAPS = 1: dW[ci][co] = X^T dY over the rows).  Both operands sit pixel-major
 // in LDS exactly as they come from HBM; the MFMA fragments (8 consecutive pixels
 // of one channel) are read with the transposing ds_read_b64_tr_b16.
-// Grid: (Cin/64, Cout/64, TAPS * splitk); each block adds its slice with
-// float32 atomics into the zeroed dW.
+// A workgroup owns a TM x TN (ci x co) tile of one tap and one slice of the
+// pixels; four waves split it 2 x 2.  Slices are dealt to the XCDs in contiguous
+// runs so that all tiles and taps of a slice read it through one L2.  With more
+// than one slice the partial tiles are added with float32 atomics into the
+// zeroed dW.
 // ---------------------------------------------------------------------------
+template <int PITCH>
 __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int mbase, int lane) {
   // lanes 16g..16g+15: block of 4 pixel rows x 16 channels; lane 4q+p gives row q, channels 4p..4p+3
   const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3, h = g >> 1;
-  const bf16* a0 = tile + (k0 + 8 * h + q) * LDS_PITCH + mbase + (g & 1) * 16 + 4 * p;
+  const bf16* a0 = tile + (k0 + 8 * h + q) * PITCH + mbase + (g & 1) * 16 + 4 * p;
   const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)a0);
-  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 4 * LDS_PITCH));
+  const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(a0 + 4 * PITCH));
   bf16x8 f;
   const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
 #pragma unroll
@@ -185,31 +189,50 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int mbase, i
   return f;
 }
 
-template <int TAPS>
+template <int TAPS, int TM, int TN>
 __global__ void __launch_bounds__(256)
 wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P, int Cin,
-                  int Cout, int H, int W, int splitk) {
-  __shared__ __attribute__((aligned(16))) bf16 Xs[64 * LDS_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16 Ys[64 * LDS_PITCH];
+                  int Cout, int H, int W, int splitk, int total_work) {
+  // row pitch = payload + 64 bytes: the 4 rows x 2 column halves that 32 lanes of a
+  // transposing read touch then fall into 8 distinct 32-byte bank groups
+  constexpr int PX = TM + 32, PY = TN + 32;
+  constexpr int MT = TM / 64, NT = TN / 64;     // 32x32 MFMA tiles per wave along ci / co
+  constexpr int XV = TM / 32, YV = TN / 32;     // 16-byte loads per thread per 64-pixel step
+  __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PY];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
-  const int tap = blockIdx.z / splitk, slice = blockIdx.z - tap * splitk;
+
+  const int per_xcd = (total_work + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_work) return;
+  const int ci_tiles = Cin / TM, co_tiles = Cout / TN, tiles = ci_tiles * co_tiles * TAPS;
+  const int slice = work / tiles;
+  int rest = work - slice * tiles;
+  const int tap = rest / (ci_tiles * co_tiles);
+  rest -= tap * ci_tiles * co_tiles;
+  const int ci0 = (rest / co_tiles) * TM, co0 = (rest % co_tiles) * TN;
   const int dy = TAPS == 9 ? tap / 3 - 1 : 0, dx = TAPS == 9 ? tap % 3 - 1 : 0;
-  const int chunk = (P + splitk - 1) / splitk;
+  // slices are multiples of 64 pixels so that every step but the last is full
+  const int chunk = (((P + splitk - 1) / splitk) + 63) & ~63;
   const int p_begin = slice * chunk, p_end = min(P, p_begin + chunk);
 
-  // loader: thread -> pixel row tid>>2 of the 64-pixel step, 32-byte quarter tid&3.  Rows past
-  // the slice and taps outside the image read a valid dummy address and are zeroed by mask.
+  // loader: thread -> pixel row tid>>2 of the 64-pixel step, quarter tid&3 of the channels.
+  // Rows past the slice and taps outside the image read a valid dummy address and are
+  // zeroed by mask.
   const int l_row = tid >> 2, l_q = tid & 3;
-  f32x16 acc;
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-  uint4 rx0, rx1, ry0, ry1;
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  uint4 rx[XV], ry[YV];
   uint32_t keep_x = 0u, keep_y = 0u;
   const int hw = H * W;
-  const bf16* x_col = X + ci0 + l_q * 16;
-  const bf16* y_col = dY + co0 + l_q * 16;
+  const bf16* x_col = X + ci0 + l_q * (TM / 4);
+  const bf16* y_col = dY + co0 + l_q * (TN / 4);
 
 #define SLAMHIP_WGRAD_ISSUE(p0)                                                                     \
   {                                                                                                 \
@@ -225,7 +248,8 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
     }                                                                                               \
     const uint4* xs = reinterpret_cast<const uint4*>(x_col + xo);                                   \
     const uint4* ys = reinterpret_cast<const uint4*>(y_col + (long long)pc * Cout);                 \
-    rx0 = xs[0]; rx1 = xs[1]; ry0 = ys[0]; ry1 = ys[1];                                             \
+    _Pragma("unroll") for (int i = 0; i < XV; ++i) rx[i] = xs[i];                                   \
+    _Pragma("unroll") for (int i = 0; i < YV; ++i) ry[i] = ys[i];                                   \
     keep_x = x_ok ? 0xffffffffu : 0u;                                                               \
     keep_y = in_slice ? 0xffffffffu : 0u;                                                           \
   }
@@ -234,31 +258,41 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
   for (int p0 = p_begin; p0 < p_end; p0 += 64) {
     __syncthreads();
     {
-      uint4* xd = reinterpret_cast<uint4*>(&Xs[l_row * LDS_PITCH + l_q * 16]);
-      uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * LDS_PITCH + l_q * 16]);
-      xd[0] = and4(rx0, keep_x); xd[1] = and4(rx1, keep_x);
-      yd[0] = and4(ry0, keep_y); yd[1] = and4(ry1, keep_y);
+      uint4* xd = reinterpret_cast<uint4*>(&Xs[l_row * PX + l_q * (TM / 4)]);
+      uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * PY + l_q * (TN / 4)]);
+#pragma unroll
+      for (int i = 0; i < XV; ++i) xd[i] = and4(rx[i], keep_x);
+#pragma unroll
+      for (int i = 0; i < YV; ++i) yd[i] = and4(ry[i], keep_y);
     }
     __syncthreads();
     if (p0 + 64 < p_end) SLAMHIP_WGRAD_ISSUE(p0 + 64);
 #pragma unroll
     for (int kk = 0; kk < 64; kk += 16) {
-      const bf16x8 af = tr_frag(Xs, kk, wm * 32, lane);   // A[m = ci][k = pixel]
-      const bf16x8 bf = tr_frag(Ys, kk, wn * 32, lane);   // B[k = pixel][n = co]
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      bf16x8 af[MT], bfr[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = tr_frag<PX>(Xs, kk, wm * (TM / 2) + i * 32, lane);    // A[m = ci][k = pixel]
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bfr[j] = tr_frag<PY>(Ys, kk, wn * (TN / 2) + j * 32, lane);   // B[k = pixel][n = co]
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
 #undef SLAMHIP_WGRAD_ISSUE
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int co = co0 + wn * 32 + (lane & 31);
-    if (ci < Cin && co < Cout) {
-      float* dst = &dW[((long long)tap * Cin + ci) * Cout + co];
-      if (splitk == 1) *dst = acc[r];   // the only contribution: plain store, dW needs no zero-fill
-      else atomicAdd(dst, acc[r]);
-    }
-  }
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * (TN / 2) + j * 32 + (lane & 31);
+        float* dst = &dW[((long long)tap * Cin + ci) * Cout + co];
+        if (splitk == 1) *dst = acc[i][j][r];   // the only contribution: plain store, dW needs no zero-fill
+        else atomicAdd(dst, acc[i][j][r]);
+      }
 }
 
 // ---------------------------------------------------------------------------
@@ -720,21 +754,37 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   hipStream_t s = (hipStream_t)stream;
   const long long P = (long long)B * H * W;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "wgrad: too many pixels");
-  const long long tiles = (long long)(Cin / 64) * (Cout / 64) * taps;
-  long long splitk = (2048 + tiles - 1) / tiles;                      // aim at >= 2048 workgroups
-  const long long max_split = (P + 255) / 256;                          // at least 256 pixels per slice
+  const int TM = Cin % 128 == 0 ? 128 : 64, TN = Cout % 128 == 0 ? 128 : 64;
+  const long long tiles = (long long)(Cin / TM) * (Cout / TN) * taps;
+  long long splitk = (1024 + tiles - 1) / tiles;                      // aim at >= 1024 workgroups
+  const long long max_split = (P + 511) / 512;                          // at least 512 pixels per slice
   if (splitk > max_split) splitk = max_split;
   if (splitk < 1) splitk = 1;
-  if (taps * splitk > 65535) splitk = 65535 / taps;
+  // slices are rounded up to 64 pixels; drop the ones that rounding leaves empty
+  if (P > 0) {
+    const long long chunk = ((P + splitk - 1) / splitk + 63) / 64 * 64;
+    splitk = (P + chunk - 1) / chunk;
+  }
   if (splitk != 1 || P == 0) SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)taps * Cin * Cout, s));
   if (P == 0) return SLAMHIP_OK;
-  const dim3 grid(Cin / 64, Cout / 64, (unsigned)(taps * splitk));
-  if (taps == 9)
-    hipLaunchKernelGGL(wgrad_bf16_kernel<9>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, (int)P, Cin,
-                       Cout, H, W, (int)splitk);
-  else
-    hipLaunchKernelGGL(wgrad_bf16_kernel<1>, grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw, (int)P, Cin,
-                       Cout, H, W, (int)splitk);
+  const long long total = tiles * splitk;
+  SLAMHIP_REQUIRE(total < (1LL << 30), SLAMHIP_E_SIZE, "wgrad: too many workgroups");
+  const dim3 grid((unsigned)((total + 7) / 8 * 8));
+#define SLAMHIP_WGRAD_GO(TAPS_, TM_, TN_)                                                                          \
+  hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, TM_, TN_>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, \
+                     dw, (int)P, Cin, Cout, H, W, (int)splitk, (int)total)
+  if (taps == 9) {
+    if (TM == 128 && TN == 128) SLAMHIP_WGRAD_GO(9, 128, 128);
+    else if (TM == 64 && TN == 128) SLAMHIP_WGRAD_GO(9, 64, 128);
+    else if (TM == 128 && TN == 64) SLAMHIP_WGRAD_GO(9, 128, 64);
+    else SLAMHIP_WGRAD_GO(9, 64, 64);
+  } else {
+    if (TM == 128 && TN == 128) SLAMHIP_WGRAD_GO(1, 128, 128);
+    else if (TM == 64 && TN == 128) SLAMHIP_WGRAD_GO(1, 64, 128);
+    else if (TM == 128 && TN == 64) SLAMHIP_WGRAD_GO(1, 128, 64);
+    else SLAMHIP_WGRAD_GO(1, 64, 64);
+  }
+#undef SLAMHIP_WGRAD_GO
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
