@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--factor", type=float, default=1.0, help="depth divisor (1 = reference, 5000 = metric)")
     ap.add_argument("--depth", default="plane", choices=["plane", "noise"])
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--encoder-steps", type=int, default=3,
+                    help="training steps of the pose-regression encoder timed after the headline "
+                         "measurement and reported under the 'encoder' key (0 = skip)")
     return ap.parse_args()
 
 
@@ -136,6 +139,29 @@ def main():
         elapsed = float(t.item())
     launch_ms = ev0.elapsed_time(ev1) / max(1, a.steps)
 
+    # Secondary measurement (never part of `value`): the encoder's training step, batch 128 on
+    # one GPU, 64 per GPU data-parallel with the RCCL gradient all-reduce on several.
+    encoder = None
+    if a.encoder_steps > 0:
+        try:
+            from slam_amd.network.cnn_model import timed_training_steps
+            enc = timed_training_steps(128 if world == 1 else 64, a.encoder_steps, warmup=2, seed=rank)
+            if dist is not None:
+                t = torch.tensor([enc["step_ms"]], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                enc["step_ms"] = float(t.item())
+            peak = 2500.0   # dense bf16 MFMA TFLOP/s of one MI355X
+            tfl = enc["tflop_per_step"] / (enc["step_ms"] * 1e-3)
+            encoder = {"workload": "VGG16-style pose encoder training step (forward, loss, backward, %sAdam), "
+                                   "224x224x4 input, bf16 operands / f32 accumulate, batch %d per GPU"
+                                   % ("RCCL gradient all-reduce, " if world > 1 else "", enc["batch_per_gpu"]),
+                       "images_per_s": world * enc["batch_per_gpu"] / (enc["step_ms"] * 1e-3),
+                       "step_ms": enc["step_ms"], "steps": a.encoder_steps,
+                       "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
+                                    "frac": tfl / peak, "flops": "model FLOPs of the whole step / step time, per GPU"}}
+        except Exception as e:   # the headline line must survive a failure here
+            encoder = {"error": "%s: %s" % (type(e).__name__, e)}
+
     if rank == 0:
         # the last step ran on bufs[(steps-1) % nb]; check its first pair against the C oracle
         last = bufs[(a.steps - 1) % len(bufs)] if a.steps else bufs[0]
@@ -174,6 +200,7 @@ def main():
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * B},
             "cpu_baseline": cb,
             "verified_against_oracle": verified,
+            "encoder": encoder,
         }
         print(json.dumps(line))
     if dist is not None:

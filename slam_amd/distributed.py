@@ -1,0 +1,58 @@
+"""Data-parallel plumbing of the frame-pair path: one process per GPU under
+torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in CPU tests).
+
+Frame pairs are independent, so the per-pixel kernels need no collective: each
+rank owns a contiguous shard of the pairs.  The only exchanges are the totals of
+the reduced residuals (a few numbers per step) and, when the encoder trains, the
+gradient mean, sent as two buckets so that the first all-reduce overlaps the rest
+of the backward pass.
+"""
+import torch
+import torch.distributed as dist
+
+
+def initialised():
+    return dist.is_available() and dist.is_initialized()
+
+
+def world_size():
+    return dist.get_world_size() if initialised() else 1
+
+
+def rank():
+    return dist.get_rank() if initialised() else 0
+
+
+def shard_range(n_items, rank_=None, world=None):
+    """[begin, end) of the items rank owns: contiguous, sizes differ by at most one, the
+    first n_items % world ranks hold the extra item."""
+    r = rank() if rank_ is None else rank_
+    w = world_size() if world is None else world
+    base, extra = divmod(int(n_items), w)
+    begin = r * base + min(r, extra)
+    return begin, begin + base + (1 if r < extra else 0)
+
+
+def start_bucket_allreduce(flat, begin, end):
+    """Asynchronous sum of flat[begin:end] over the ranks; returns the work handle (None
+    without a process group)."""
+    if not initialised() or end <= begin:
+        return None
+    return dist.all_reduce(flat[begin:end], op=dist.ReduceOp.SUM, async_op=True)
+
+
+def finish(handles):
+    for h in handles:
+        if h is not None:
+            h.wait()
+
+
+def total_pair_sums(sums, counts):
+    """Sum the per-pair reductions of this rank's shard and add them up over the ranks:
+    returns (float64 [4] sums, int64 [4] counts) of the whole job on every rank."""
+    s = sums.reshape(-1, sums.shape[-1]).sum(0).to(torch.float64)
+    c = counts.reshape(-1, counts.shape[-1]).to(torch.int64).sum(0)
+    if initialised():
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+    return s, c

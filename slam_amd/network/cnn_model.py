@@ -37,6 +37,51 @@ def _round_up(n, m):
     return (n + m - 1) // m * m
 
 
+def model_flops(batch, height, width, in_channels=4, fc_dim=4096, output_dim=6):
+    """(forward, forward + backward) floating-point operations of one step, a multiply-add
+    counted as two; backward = data gradient + weight gradient of every layer, except that
+    the first layer has no data gradient."""
+    fwd, first = 0, None
+    h, w, c = height, width, in_channels
+    for _, cout, pool in CONV_LAYERS:
+        f = 2 * batch * h * w * 9 * c * cout
+        first = f if first is None else first
+        fwd += f
+        c = cout
+        if pool:
+            h, w = h // 2, w // 2
+    fwd += 2 * batch * (h * w * c * fc_dim + fc_dim * fc_dim + fc_dim * output_dim)
+    return fwd, 3 * fwd - first
+
+
+def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0):
+    """Random-initialised encoder on synthetic input: `steps` training steps (forward, loss,
+    backward, gradient all-reduce when torch.distributed is initialised, Adam) timed with
+    one event pair on the launching stream.  Returns a dict for benchmark reports."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(batch, height, width, 4, device=dev, generator=g)
+    model = VGG16Model(batch, x, 6, 1e-3, seed=seed)
+    model.build_graph()
+    model.add_loss(torch.eye(6, device=dev), 0.1 * torch.randn(batch, 6, device=dev, generator=g))
+    step = model.add_optimizer()
+    model._optimizer.learning_rate = 1e-5
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    step_ms = e0.elapsed_time(e1) / max(1, steps)
+    _, flops = model_flops(batch, height, width, 4, model.fc_dim, 6)
+    return dict(batch_per_gpu=batch, step_ms=step_ms, images_per_s_per_gpu=batch / (step_ms * 1e-3),
+                tflop_per_step=flops / 1e12, achieved_tflops_per_gpu=flops / 1e12 / (step_ms * 1e-3),
+                loss=float(model.loss), parameters=int(model.total_weights))
+
+
 class _Optimizer:
     """Update rule + hyper-parameters of one tf.train optimizer (cnn_model.py:162-170)."""
 
@@ -343,17 +388,16 @@ class VGG16Model:
 
     def train_step(self):
         """forward, loss, backward, gradient mean over the data-parallel ranks, update."""
-        import torch.distributed as dist
-        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        from .. import distributed as dp
+        world = dp.world_size()
         self.forward()
         self.compute_loss(with_gradient=True)
-        pending = []
-        if world > 1:
-            fc_bucket = self.flat_grads[:self._fc_end]
-            self.backward(on_fc_done=lambda: pending.append(dist.all_reduce(fc_bucket, async_op=True)))
-            pending.append(dist.all_reduce(self.flat_grads[self._fc_end:], async_op=True))
-            for w in pending:
-                w.wait()
+        if dp.initialised():
+            pending = []
+            self.backward(on_fc_done=lambda: pending.append(
+                dp.start_bucket_allreduce(self.flat_grads, 0, self._fc_end)))
+            pending.append(dp.start_bucket_allreduce(self.flat_grads, self._fc_end, self._nparams))
+            dp.finish(pending)
         else:
             self.backward()
         self._apply_gradients(1.0 / world)

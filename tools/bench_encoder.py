@@ -11,28 +11,9 @@ import time
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from slam_amd.network.cnn_model import CONV_LAYERS, VGG16Model   # noqa: E402
+from slam_amd.network.cnn_model import VGG16Model, model_flops   # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0
-
-
-def model_flops(B, H, W, cin, fc_dim, out_dim):
-    """multiply-add = 2 FLOPs; forward, and forward + data gradient + weight gradient."""
-    fwd = 0
-    h, w, c = H, W, cin
-    first = None
-    for name, cout, pool in CONV_LAYERS:
-        f = 2 * B * h * w * 9 * c * cout
-        if first is None:
-            first = f
-        fwd += f
-        c = cout
-        if pool:
-            h, w = h // 2, w // 2
-    feat = h * w * c
-    fc = 2 * B * (feat * fc_dim + fc_dim * fc_dim + fc_dim * out_dim)
-    fwd += fc
-    return fwd, 3 * fwd - first     # the first layer has no data gradient
 
 
 def main():
