@@ -78,7 +78,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or "LOCAL_RANK" in os.environ:   # under torch.distributed.run, a group of one too
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
@@ -154,7 +154,7 @@ def main():
             tfl = enc["tflop_per_step"] / (enc["step_ms"] * 1e-3)
             encoder = {"workload": "VGG16-style pose encoder training step (forward, loss, backward, %sAdam), "
                                    "224x224x4 input, bf16 operands / f32 accumulate, batch %d per GPU"
-                                   % ("RCCL gradient all-reduce, " if world > 1 else "", enc["batch_per_gpu"]),
+                                   % ("RCCL gradient all-reduce, " if dist is not None else "", enc["batch_per_gpu"]),
                        "images_per_s": world * enc["batch_per_gpu"] / (enc["step_ms"] * 1e-3),
                        "step_ms": enc["step_ms"], "steps": a.encoder_steps,
                        "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
