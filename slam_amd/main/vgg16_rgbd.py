@@ -1,0 +1,103 @@
+"""VGG16 with the RGB-D dataset: the training entry point of the reference
+(slam/main/vgg16_rgbd.py:13-66) on the MI355X kernels.
+
+  python -m slam_amd.main.vgg16_rgbd                       # resources/model.config, TUM directories
+  python -m slam_amd.main.vgg16_rgbd --synthetic /tmp/tum --max-steps 8
+  python -m torch.distributed.run --nproc-per-node 8 -m slam_amd.main.vgg16_rgbd ...   # data parallel
+
+Same flow as the reference: configuration from resources/model.config, a
+[batch, 224, 224, 4] input and a [batch, 6] ground-truth buffer refilled per step
+(the reference's placeholders), loss weight zero for the first batch of a sequence
+and identity afterwards, weights saved every 10 epochs.  TensorFlow summaries and
+the checkpoint format are not reproduced; weights are saved with torch.save.
+"""
+import argparse
+import logging
+import os
+
+import numpy as np
+import torch
+
+from slam_amd.network.cnn_model import VGG16Model
+from slam_amd.network.model_config import get_config_provider
+from slam_amd.network.model_input import get_simple_input_provider, write_synthetic_sequence
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data-dir", default=None, help="directory holding the sequence directories "
+                                                     "(default: the reference's BASE_DATA_DIR)")
+    ap.add_argument("--synthetic", default=None, metavar="DIR",
+                    help="write synthetic TUM-shaped sequences for the configured names into DIR and train on them")
+    ap.add_argument("--synthetic-frames", type=int, default=8)
+    ap.add_argument("--max-steps", type=int, default=0, help="stop after this many training steps (0 = no limit)")
+    ap.add_argument("--epochs", type=int, default=0, help="override the configured number of epochs")
+    a = ap.parse_args(argv)
+
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    logger = logging.getLogger("slam_amd")
+    img_h = img_w = 224
+    config_provider = get_config_provider()
+    base_dir = config_provider.base_log_dir()
+    weights_file = os.path.join(base_dir, 'checkpoints', 'learned_weights.pt')
+    epoch = a.epochs or config_provider.epoch()
+    batch_size = config_provider.batch_size()
+    normalization_epsilon = config_provider.normalization_epsilon()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    data_dir = a.data_dir
+    if a.synthetic:
+        data_dir = a.synthetic
+        if local == 0:
+            for i, name in enumerate(config_provider.training_filenames()):
+                if not os.path.exists(os.path.join(data_dir, name, "associate.txt")):
+                    write_synthetic_sequence(os.path.join(data_dir, name), a.synthetic_frames, seed=i)
+        if world > 1:
+            dist.barrier()
+
+    rgbd_input_batch = torch.zeros(batch_size, img_h, img_w, 4, dtype=torch.float32, device=dev)
+    groundtruth_batch = torch.zeros(batch_size, 6, dtype=torch.float32, device=dev)
+    loss_weight = torch.zeros(6, 6, dtype=torch.float32, device=dev)
+
+    vgg_model = VGG16Model(batch_size, rgbd_input_batch, 6, normalization_epsilon)
+    vgg_model.build_graph()
+    loss = vgg_model.add_loss(loss_weight, groundtruth_batch)
+    apply_gradient_op = vgg_model.add_optimizer()
+
+    input_provider = get_simple_input_provider(config_provider.training_filenames, base_data_dir=data_dir)
+    steps, loss_value = 0, float("nan")
+    for step in range(epoch):
+        logger.info('Executing step:%d', step)
+        for i, sequence_batch in enumerate(input_provider.complete_seq_iter()):
+            rgbd_input_batch.copy_(torch.from_numpy(np.stack(sequence_batch.rgbd_images)))
+            groundtruth_batch.copy_(torch.from_numpy(np.stack(sequence_batch.groundtruths).astype(np.float32)))
+            # the first frame of a sequence has no motion label: zero weight (vgg16_rgbd.py:51)
+            loss_weight.copy_(torch.zeros(6, 6) if i == 0 else torch.eye(6))
+            apply_gradient_op()
+            loss_value = float(loss)
+            logger.info('epoc:%d, seq_no:%d loss :%s', step, i, loss_value)
+            steps += 1
+            if a.max_steps and steps >= a.max_steps:
+                break
+        if step % 10 == 0 and local == 0:
+            logger.info('Saving weights.')
+            os.makedirs(os.path.dirname(weights_file) or ".", exist_ok=True)
+            torch.save({k: v.cpu() for k, v in vgg_model.params.items()}, weights_file)
+        logger.info('epoc:%d, loss:%s', step, loss_value)
+        if a.max_steps and steps >= a.max_steps:
+            break
+    if world > 1:
+        dist.destroy_process_group()
+    return loss_value
+
+
+if __name__ == '__main__':
+    main()

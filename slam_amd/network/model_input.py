@@ -1,0 +1,189 @@
+"""Input provider of the RGB-D trainers with the reference's class, method and
+attribute names (slam/network/model_input.py:322-454, 517-529).
+
+Per sequence directory it reads `associate.txt` and `groundtruth.txt`,
+precomputes the per-frame twist label from the ABSOLUTE pose (the reference never
+uses its `trans_old`, model_input.py:387-394) through the C ABI's host pose
+functions, and yields one frame per sequence per step: RGB + depth read, depth
+scaled to `255 * d / max(d)`, 4-channel concat, bilinear resize to 224x224,
+per-batch channel-mean subtraction.
+
+Two points where the reference's libraries are not available here (parity
+unpinned, behaviour chosen and stated):
+  * `255 * depth / np.max(depth)` runs under Python 2 on an integer image: floor
+    division.  The 16-bit PNG is widened to int32 first (no uint16 wrap).
+  * `skimage.transform.resize(..., preserve_range=True)` is restated as order-1
+    interpolation at half-pixel centres with edge clamping.
+"""
+import os
+import random
+
+import numpy as np
+
+from .. import frame_pairs as fp
+from ..preprocess.geometry import _find_label
+
+
+def get_mean(rgb_images, channels=3):
+    """model_input.py:517-522 - mean over rows, then columns, then images."""
+    total = np.zeros(channels)
+    for image in rgb_images:
+        total += np.mean(np.mean(image, axis=0), axis=0)
+    return total / len(rgb_images)
+
+
+def read_png(path):
+    """8-bit RGB -> uint8 [H,W,3]; 16-bit grey -> int32 [H,W]."""
+    from PIL import Image
+    with Image.open(path) as im:
+        a = np.array(im)
+    return a.astype(np.int32) if a.ndim == 2 else a
+
+
+def resize_bilinear(img, out_h, out_w):
+    """[H,W,C] float -> [out_h,out_w,C]: order-1 interpolation, sample centres at
+    (i + 0.5) * H / out_h - 0.5, clamped to the image."""
+    img = np.asarray(img, np.float64)
+    H, W = img.shape[:2]
+    ys = np.clip((np.arange(out_h) + 0.5) * H / out_h - 0.5, 0, H - 1)
+    xs = np.clip((np.arange(out_w) + 0.5) * W / out_w - 0.5, 0, W - 1)
+    y0 = np.floor(ys).astype(int)
+    x0 = np.floor(xs).astype(int)
+    y1 = np.minimum(y0 + 1, H - 1)
+    x1 = np.minimum(x0 + 1, W - 1)
+    fy = (ys - y0)[:, None, None]
+    fx = (xs - x0)[None, :, None]
+    top = img[y0][:, x0] * (1 - fx) + img[y0][:, x1] * fx
+    bot = img[y1][:, x0] * (1 - fx) + img[y1][:, x1] * fx
+    return top * (1 - fy) + bot * fy
+
+
+def absolute_twist_labels(gt_rows):
+    """model_input.py:384-396 - twist of the absolute pose for i > 0, zeros for i = 0
+    (clamped-trace variant of _trans_to_twist, model_input.py:46-76)."""
+    gt_rows = np.ascontiguousarray(gt_rows, np.float32)
+    twist = np.zeros((gt_rows.shape[0], 6))
+    if gt_rows.shape[0] > 1:
+        T = fp.quat_to_transformation_batch(gt_rows[1:])
+        twist[1:] = fp.trans_to_twist_batch(T, clamp=True)
+    return twist
+
+
+class SimpleInputProvider:
+
+    class SequenceBatch:
+
+        def __init__(self):
+            self.rgb_filenames = []
+            self.depth_filenames = []
+            self.rgbd_images = []
+            self.groundtruths = []
+
+    class SequenceBatchIterator:
+        """One frame of every (sequence, offset) entry per step, offsets advancing
+        (model_input.py:333-367)."""
+
+        def __init__(self, input_provider, seqdir_vs_offset, sequence_length):
+            self.counter = 0
+            self.seqdir_vs_offset = seqdir_vs_offset
+            self.input_provider = input_provider
+            self.sequence_length = sequence_length
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            if self.counter >= self.sequence_length:
+                raise StopIteration()
+            batch = SimpleInputProvider.SequenceBatch()
+            for i, (seqdir, offset) in enumerate(self.seqdir_vs_offset):
+                rgb_filename, depth_filename, rgbd = self.input_provider.get_rgbd_file(seqdir, offset)
+                batch.rgbd_images.append(rgbd)
+                batch.groundtruths.append(self.input_provider.get_ground_truth(seqdir, offset))
+                batch.rgb_filenames.append(rgb_filename)
+                batch.depth_filenames.append(depth_filename)
+                self.seqdir_vs_offset[i][1] = offset + 1
+            mean = get_mean(batch.rgbd_images, channels=4)
+            batch.rgbd_images = [image - mean for image in batch.rgbd_images]
+            self.counter += 1
+            return batch
+
+        next = __next__
+
+    BASE_DATA_DIR = '/usr/data/rgbd_datasets/tum_rgbd_benchmark/'
+
+    def __init__(self, filename_provider, base_data_dir=None, image_reader=read_png):
+        base = self.BASE_DATA_DIR if base_data_dir is None else base_data_dir
+        self.sequence_dirs = [os.path.join(base, name) for name in filename_provider()]
+        self.image_reader = image_reader
+        self.seq_dir_map = {}
+        for seq_dir in self.sequence_dirs:
+            associations = np.loadtxt(os.path.join(seq_dir, "associate.txt"), dtype="str", unpack=False)
+            groundtruth = np.loadtxt(os.path.join(seq_dir, "groundtruth.txt"), dtype="str", unpack=False)
+            rows = np.array([groundtruth[:, 1:][min(_find_label(groundtruth[:, 0], stamp), len(groundtruth) - 1)]
+                             for stamp in associations[:, 0]]).astype(np.float32)
+            self.seq_dir_map[seq_dir] = dict(associations=associations, groundtruth=groundtruth,
+                                             relpos=absolute_twist_labels(rows))
+
+    def sequence_batch_itr(self, sequence_length, batch_size):
+        """model_input.py:398-411."""
+        random.shuffle(self.sequence_dirs)
+        seqdir_vs_offset = []
+        for i in range(batch_size):
+            seq_dir = self.sequence_dirs[i % len(self.sequence_dirs)]
+            total_frames = len(self.seq_dir_map[seq_dir]['associations'])
+            seqdir_vs_offset.append([seq_dir, random.randint(0, total_frames - sequence_length)])
+        return self.SequenceBatchIterator(self, seqdir_vs_offset, sequence_length)
+
+    def complete_seq_iter(self):
+        """All frames of one randomly chosen sequence (model_input.py:417-425)."""
+        random.shuffle(self.sequence_dirs)
+        seq_dir = self.sequence_dirs[0]
+        total_frames = len(self.seq_dir_map[seq_dir]['associations'])
+        return self.SequenceBatchIterator(self, [[seq_dir, 0]], total_frames)
+
+    def get_rgbd_file(self, dirname, offset):
+        """model_input.py:427-450 -> (rgb path, depth path, float32 [224,224,4])."""
+        associations = self.seq_dir_map[dirname]['associations']
+        if associations[offset, 1].startswith('depth'):
+            rgb_filename = os.path.join(dirname, associations[offset, 3])
+            depth_filename = os.path.join(dirname, associations[offset, 1])
+        else:
+            rgb_filename = os.path.join(dirname, associations[offset, 1])
+            depth_filename = os.path.join(dirname, associations[offset, 3])
+        rgb_img = self.image_reader(rgb_filename)
+        depth_img = np.asarray(self.image_reader(depth_filename)).astype(np.int64)
+        depth_img = depth_img.reshape(list(depth_img.shape) + [1])
+        depth_img = 255 * depth_img // max(int(np.max(depth_img)), 1)    # Python-2 integer division
+        rgbd_img = np.concatenate((rgb_img, depth_img), 2)
+        rgbd_img = resize_bilinear(rgbd_img, 224, 224)
+        return rgb_filename, depth_filename, rgbd_img.astype(np.float32)
+
+    def get_ground_truth(self, dirname, offset):
+        return self.seq_dir_map[dirname]['relpos'][offset, :]
+
+
+def get_simple_input_provider(filename_provider, base_data_dir=None):
+    """model_input.py:528-529."""
+    return SimpleInputProvider(filename_provider, base_data_dir=base_data_dir)
+
+
+def write_synthetic_sequence(seq_dir, n_frames=12, height=480, width=640, seed=0):
+    """A TUM-shaped sequence directory (rgb/*.png, depth/*.png 16-bit, associate.txt,
+    groundtruth.txt) of synthetic frames, for runs without the dataset."""
+    from PIL import Image
+    from ..utils import synthetic as syn
+    os.makedirs(os.path.join(seq_dir, "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(seq_dir, "depth"), exist_ok=True)
+    depth = syn.depth_frames(n_frames, height, width, seed=seed, kind="plane")
+    rgb = syn.rgb_frames(n_frames, height, width, seed=seed, kind="smooth")
+    poses = syn.pose_pairs(n_frames, seed=seed)[:, 1]
+    with open(os.path.join(seq_dir, "associate.txt"), "w") as fa, \
+            open(os.path.join(seq_dir, "groundtruth.txt"), "w") as fg:
+        for i in range(n_frames):
+            stamp = "%.4f" % (1305031100.0 + i / 30.0)
+            Image.fromarray(rgb[i]).save(os.path.join(seq_dir, "rgb", stamp + ".png"))
+            Image.fromarray(depth[i]).save(os.path.join(seq_dir, "depth", stamp + ".png"))
+            fa.write("%s rgb/%s.png %s depth/%s.png\n" % (stamp, stamp, stamp, stamp))
+            fg.write(stamp + " " + " ".join("%.6f" % v for v in poses[i]) + "\n")
+    return seq_dir

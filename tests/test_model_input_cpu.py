@@ -1,0 +1,67 @@
+"""The input provider on a synthetic TUM-shaped directory (CPU only): labels
+against the oracle's restatement of model_input.py:384-396, per-batch mean
+subtraction against get_mean (:517-522, golden-pinned in test_oracle_golden),
+the Python-2 integer depth scaling, iterator semantics.
+"""
+import numpy as np
+import pytest
+
+from oracle import slam_oracle as so
+from slam_amd.network import model_input as mi
+
+
+@pytest.fixture(scope="module")
+def provider(tmp_path_factory):
+    base = tmp_path_factory.mktemp("tum")
+    names = ["seq_a", "seq_b"]
+    for i, n in enumerate(names):
+        mi.write_synthetic_sequence(str(base / n), n_frames=5, height=48, width=64, seed=i)
+    return mi.SimpleInputProvider(lambda: list(names), base_data_dir=str(base)), base, names
+
+
+def test_labels_are_absolute_twists(provider):
+    p, base, names = provider
+    for seq_dir, entry in p.seq_dir_map.items():
+        gt = entry["groundtruth"]
+        rows = np.array([gt[:, 1:][so.find_label(gt[:, 0], s)] for s in entry["associations"][:, 0]]).astype(np.float32)
+        want = so.absolute_twist_labels(rows)
+        np.testing.assert_allclose(entry["relpos"], want, rtol=1e-11, atol=1e-13)
+        assert not entry["relpos"][0].any() and entry["relpos"][1:].any()
+
+
+def test_get_mean_matches_oracle():
+    rs = np.random.RandomState(0)
+    imgs = [rs.uniform(0, 255, (7, 9, 4)) for _ in range(3)]
+    np.testing.assert_allclose(mi.get_mean(imgs, channels=4), so.get_mean(imgs, channels=4), rtol=1e-15)
+
+
+def test_rgbd_frame_and_batches(provider):
+    p, base, names = provider
+    seq = p.sequence_dirs[0]
+    rgb_name, depth_name, img = p.get_rgbd_file(seq, 1)
+    assert img.shape == (224, 224, 4) and img.dtype == np.float32
+    assert "rgb/" in rgb_name and "depth/" in depth_name
+    d = mi.read_png(depth_name)
+    assert d.dtype == np.int32 and d.max() > 255
+    # depth channel: integer 255*d//max, then interpolation stays inside [0, 255]
+    assert 0 <= img[..., 3].min() and img[..., 3].max() <= 255
+    scaled = 255 * d.astype(np.int64) // d.max()
+    assert abs(float(img[..., 3].mean()) - float(scaled.mean())) < 2.0
+    it = p.sequence_batch_itr(3, 4)
+    batches = list(it)
+    assert len(batches) == 3
+    for b in batches:
+        assert len(b.rgbd_images) == 4 and len(b.groundtruths) == 4
+        # per-batch channel means are removed
+        np.testing.assert_allclose(np.mean(np.stack(b.rgbd_images), axis=(0, 1, 2)), 0.0, atol=1e-3)
+    full = list(p.complete_seq_iter())
+    assert len(full) == 5 and len(full[0].rgbd_images) == 1
+    assert not np.any(full[0].groundtruths[0])      # first frame: zero label
+
+
+def test_resize_is_identity_at_same_size_and_exact_on_ramps():
+    x = np.arange(12.0).reshape(3, 4, 1)
+    assert np.array_equal(mi.resize_bilinear(x, 3, 4), x)
+    ramp = np.tile(np.arange(8.0)[None, :, None], (4, 1, 1))
+    out = mi.resize_bilinear(ramp, 4, 4)
+    np.testing.assert_allclose(out[0, :, 0], [0.5, 2.5, 4.5, 6.5])
