@@ -212,6 +212,26 @@ int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad,
 int slamhip_l2loss(const float* out, const float* gt, const float* loss_weight, float* loss,
                    float* d_out, int B, int D, void* stream);
 
+/* slam/network/lstm_model.py:52-55 and the general form of the loss above:
+ * loss[0] = scale * sum(((out - gt) . loss_weight)^2), d_out its gradient
+ * (scale = 1/B gives the LSTM trainer's loss, 0.5 gives slamhip_l2loss). */
+int slamhip_weighted_sq_loss(const float* out, const float* gt, const float* loss_weight, float scale,
+                             float* loss, float* d_out, int B, int D, void* stream);
+
+/* slam/main/vgg16_posenet.py:16-25 - rows [x y z qw qx qy qz]: loss[0] =
+ * sum((x^ - x)^2) + beta * sum((q^ - q)^2) (beta = 1100 in the reference);
+ * d_out (may be NULL) [B][7]. */
+int slamhip_posenet_loss(const float* out7, const float* gt7, float beta, float* loss, float* d_out,
+                         int B, void* stream);
+
+/* slam/network/cnn_model_noBN.py:104-111 - the convolution layer without
+ * batch-norm: y = relu(z + bias) on NHWC bfloat16 z [P][C] (C % 8 == 0), and its
+ * backward: dz = dy * (y > 0), dbias[c] = sum dz (float32 [C], overwritten;
+ * C % 64 == 0). */
+int slamhip_bias_relu_fwd(const void* z, const float* bias, void* y, long long P, int C, void* stream);
+int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias, long long P, int C,
+                          void* stream);
+
 /* cnn_model.py:162-166 - tf.train.AdamOptimizer update of one parameter tensor:
  * g = grad * grad_scale; m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
  * p -= lr * sqrt(1-b2^step)/(1-b1^step) * m / (sqrt(v) + eps).  step >= 1. */

@@ -392,9 +392,10 @@ conv3x3_c4_k64_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, 
 // Column reductions over the P rows of an [P][C] bfloat16 matrix, 16 bytes (8 channels) per
 // thread per row: a block is (C/8 column groups) x (256 / (C/8) row lanes), rows strided over
 // the grid; partial sums meet in LDS and leave as 2C float atomics per block.
-//   BWD = false: out[c] += sum z,   out[C + c] += sum z^2                      (statistics)
-//   BWD = true : out[c] += sum g,   out[C + c] += sum g * xhat,  g = dy * (y > 0)
-template <bool BWD>
+//   BWD = 0: out[c] += sum z,   out[C + c] += sum z^2                        (statistics)
+//   BWD = 1: out[c] += sum g,   out[C + c] += sum g * xhat,  g = dy * (y > 0) (batch-norm backward)
+//   BWD = 2: out[c] += sum g                                                  (bias backward; out has C entries)
+template <int BWD>
 __global__ void __launch_bounds__(256)
 channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, const bf16* __restrict__ z,
                       const float* __restrict__ sums, float* __restrict__ out, int P, int C, float inv_count,
@@ -407,7 +408,7 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
 #pragma unroll
   for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 0.f; }
   if (rlane < rlanes) {
-    if (BWD) {
+    if (BWD == 1) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int c = gcol * 8 + j;
@@ -419,7 +420,7 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
     for (int p = blockIdx.x * rlanes + rlane; p < P; p += stride) {
       const long long o = ((long long)p * C >> 3) + gcol;
       const bf16x8 va = reinterpret_cast<const bf16x8*>(a)[o];
-      if (BWD) {
+      if (BWD == 1) {
         const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[o], vz = reinterpret_cast<const bf16x8*>(z)[o];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -427,6 +428,10 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
           s0[j] += g;
           s1[j] = __builtin_fmaf(g, ((float)vz[j] - mean[j]) * rstd[j], s1[j]);
         }
+      } else if (BWD == 2) {
+        const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[o];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s0[j] += ((float)vy[j] > 0.0f) ? (float)va[j] : 0.0f;
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -443,6 +448,7 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
   // thread t < 16 * groups: column group t / 16, quantity t % 16, summed over the row lanes
   for (int t = threadIdx.x; t < 16 * groups; t += 256) {
     const int gc = t >> 4, k = t & 15;
+    if (BWD == 2 && k >= 8) continue;
     float acc = 0.f;
     for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
     atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
@@ -522,6 +528,32 @@ bias_act_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ y, bf
     s += g;
   }
   dbias[n] = s;
+}
+
+// y = relu(z + bias) on NHWC bfloat16 (the convolution layer without batch-norm,
+// cnn_model_noBN.py:107-111), and the ReLU gate of its backward pass
+__global__ void __launch_bounds__(256)
+bias_relu_nhwc_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ bias, bf16* __restrict__ y,
+                          long long total8, int C) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const int c0 = (int)((i * 8) % C);
+  const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf((float)v[j] + bias[c0 + j], 0.0f);
+  reinterpret_cast<bf16x8*>(y)[i] = o;
+}
+
+__global__ void __launch_bounds__(256)
+relu_gate_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dz, long long total8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total8) return;
+  const bf16x8 vd = reinterpret_cast<const bf16x8*>(dy)[i], vy = reinterpret_cast<const bf16x8*>(y)[i];
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = ((float)vy[j] > 0.0f) ? vd[j] : (bf16)0.0f;
+  reinterpret_cast<bf16x8*>(dz)[i] = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -621,8 +653,8 @@ conv_weight_layouts_kernel(const float* __restrict__ w, bf16* __restrict__ w_fwd
 // ---------------------------------------------------------------------------
 __global__ void l2loss_kernel(const float* __restrict__ out, const float* __restrict__ gt,
                               const float* __restrict__ Wl, float* __restrict__ loss, float* __restrict__ d_out,
-                              int Bn, int D) {
-  // one block; D <= 8
+                              int Bn, int D, float scale) {
+  // one block; D <= 8.  loss = scale * sum(((out - gt) Wl)^2), d_out = 2 scale ((out - gt) Wl) Wl^T
   __shared__ float part[256];
   float acc = 0.f;
   for (int b = threadIdx.x; b < Bn; b += blockDim.x) {
@@ -638,7 +670,7 @@ __global__ void l2loss_kernel(const float* __restrict__ out, const float* __rest
       for (int i = 0; i < D; ++i) {
         float s = 0.f;
         for (int j = 0; j < D; ++j) s = __builtin_fmaf(r[j], Wl[i * D + j], s);
-        d_out[b * D + i] = s;
+        d_out[b * D + i] = 2.0f * scale * s;
       }
   }
   part[threadIdx.x] = acc;
@@ -647,7 +679,27 @@ __global__ void l2loss_kernel(const float* __restrict__ out, const float* __rest
     if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) loss[0] = 0.5f * part[0];
+  if (threadIdx.x == 0) loss[0] = scale * part[0];
+}
+
+// PoseNet loss (vgg16_posenet.py:16-25): sum((x^ - x)^2) + beta sum((q^ - q)^2), rows [x(3) q(4)]
+__global__ void posenet_loss_kernel(const float* __restrict__ out, const float* __restrict__ gt,
+                                    float* __restrict__ loss, float* __restrict__ d_out, int Bn, float beta) {
+  __shared__ float part[256];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < Bn * 7; i += blockDim.x) {
+    const float w = (i % 7) < 3 ? 1.0f : beta;
+    const float e = out[i] - gt[i];
+    acc = __builtin_fmaf(w * e, e, acc);
+    if (d_out) d_out[i] = 2.0f * w * e;
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = blockDim.x / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = part[0];
 }
 
 // ---------------------------------------------------------------------------
@@ -838,7 +890,7 @@ int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void
   if (P == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "channel_stats: more than 2048 channels");
-  hipLaunchKernelGGL(channel_reduce_kernel<false>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)z,
+  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)z,
                      (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr, sums2c, (int)P, C, 0.0f, 0.0f);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
@@ -863,7 +915,7 @@ int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const floa
   hipStream_t s = (hipStream_t)stream;
   SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
-  hipLaunchKernelGGL(channel_reduce_kernel<true>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)y, (const bf16*)z, sums2c, red2c, (int)P, C, 1.0f / (float)P, eps);
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy,
@@ -941,11 +993,51 @@ int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad,
   return SLAMHIP_OK;
 }
 
+int slamhip_weighted_sq_loss(const float* out, const float* gt, const float* loss_weight, float scale, float* loss,
+                             float* d_out, int B, int D, void* stream) {
+  SLAMHIP_REQUIRE(out && gt && loss_weight && loss && B >= 0 && D > 0 && D <= 8, SLAMHIP_E_ARG,
+                  "weighted_sq_loss: bad argument (output width must be <= 8)");
+  hipLaunchKernelGGL(l2loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, gt, loss_weight, loss, d_out, B, D,
+                     scale);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
 int slamhip_l2loss(const float* out, const float* gt, const float* loss_weight, float* loss, float* d_out, int B, int D,
                    void* stream) {
-  SLAMHIP_REQUIRE(out && gt && loss_weight && loss && B >= 0 && D > 0 && D <= 8, SLAMHIP_E_ARG,
-                  "l2loss: bad argument (output width must be <= 8)");
-  hipLaunchKernelGGL(l2loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out, gt, loss_weight, loss, d_out, B, D);
+  return slamhip_weighted_sq_loss(out, gt, loss_weight, 0.5f, loss, d_out, B, D, stream);
+}
+
+int slamhip_posenet_loss(const float* out7, const float* gt7, float beta, float* loss, float* d_out, int B,
+                         void* stream) {
+  SLAMHIP_REQUIRE(out7 && gt7 && loss && B >= 0, SLAMHIP_E_ARG, "posenet_loss: bad argument");
+  hipLaunchKernelGGL(posenet_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, out7, gt7, loss, d_out, B, beta);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bias_relu_fwd(const void* z, const float* bias, void* y, long long P, int C, void* stream) {
+  SLAMHIP_REQUIRE(z && bias && y && P >= 0 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG, "bias_relu_fwd: bad argument");
+  const long long total8 = P * C / 8;
+  if (total8 == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(bias_relu_nhwc_fwd_kernel, dim3(blocks_for(total8)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)z, bias, (bf16*)y, total8, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias, long long P, int C, void* stream) {
+  SLAMHIP_REQUIRE(dy && y && dz && dbias && P >= 0 && C > 0 && C % 64 == 0 && C <= 2048, SLAMHIP_E_ARG,
+                  "bias_relu_bwd: bad argument");
+  SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bias_relu_bwd: too many rows");
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s));
+  if (P == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
+                     (const bf16*)y, (const bf16*)nullptr, (const float*)nullptr, dbias, (int)P, C, 0.0f, 0.0f);
+  const long long total8 = P * C / 8;
+  hipLaunchKernelGGL(relu_gate_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
+                     (bf16*)dz, total8);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -93,12 +93,14 @@ class _Optimizer:
 class VGG16Model:
 
     def __init__(self, batch_size, rgbd_input_batch, output_dim, normalization_epsilon,
-                 initial_params=None, fc_dim=4096, seed=0):
+                 initial_params=None, fc_dim=4096, seed=0, batch_norm=True):
         """rgbd_input_batch: float32 GPU tensor [batch, H, W, 4] that the caller refills in
         place before each step (the reference's placeholder, main/vgg16_rgbd.py:29).
         initial_params: optional {'conv1_2': {'weights': HWIO array, 'biases': ...}, ...}
         as the reference reads from its weights file (cnn_model.py:22-23, 129-137);
-        layers without an entry (and conv1_1 always) start from a truncated normal."""
+        layers without an entry (and conv1_1 always) start from a truncated normal.
+        batch_norm=False gives the variant of slam/network/cnn_model_noBN.py:90-111:
+        conv -> bias -> ReLU instead of conv -> batch-norm -> ReLU."""
         if not (rgbd_input_batch.is_cuda and rgbd_input_batch.dtype == torch.float32
                 and rgbd_input_batch.dim() == 4 and rgbd_input_batch.shape[0] == batch_size):
             raise ValueError("rgbd_input_batch must be a float32 GPU tensor [batch, H, W, C]")
@@ -113,6 +115,7 @@ class VGG16Model:
         self.epsilon = float(normalization_epsilon)
         self.initial_params = initial_params or {}
         self.fc_dim = int(fc_dim)
+        self.batch_norm = bool(batch_norm)
         self.seed = seed
         self.total_weights = 0
         self.device = rgbd_input_batch.device
@@ -143,7 +146,10 @@ class VGG16Model:
             c_prev = cout
         for name, ci, co in reversed(conv_shapes):
             self._spec.append((name + "/weights", (3, 3, ci, co)))
-            self._spec.append((name + "/bn", (2, co)))      # row 0 beta, row 1 scale
+            if self.batch_norm:
+                self._spec.append((name + "/bn", (2, co)))      # row 0 beta, row 1 scale
+            else:
+                self._spec.append((name + "/biases", (co,)))
         offs, total = {}, 0
         for name, shape in self._spec:
             if name == "conv5_3/weights":
@@ -218,8 +224,11 @@ class VGG16Model:
         for i, (name, ci, co) in enumerate(conv_shapes):
             self.total_weights += 9 * ci * co
             self.params[name + "/weights"].copy_(initial(name, "weights", (3, 3, ci, co), allow=i > 0))
-            self.params[name + "/bn"][0].zero_()
-            self.params[name + "/bn"][1].fill_(1.0)
+            if self.batch_norm:
+                self.params[name + "/bn"][0].zero_()
+                self.params[name + "/bn"][1].fill_(1.0)
+            else:
+                self.params[name + "/biases"].copy_(initial(name, "biases", (co,), allow=i > 0))
         for name, k_in, n_out in (("fc6-conv", feat, self.fc_dim), ("fc7-conv", self.fc_dim, self.fc_dim)):
             self.params[name + "/weights"].copy_(initial(name, "weights", (k_in, n_out)))
             self.params[name + "/bias"].copy_(initial(name, "biases", (n_out,)))
@@ -260,9 +269,12 @@ class VGG16Model:
                 ops.conv3x3_small(h, self.params[n + "/weights"], a["z"])
             else:
                 ops.conv3x3(h, self._w_fwd[n], out_bf16=a["z"])
-            bn = self.params[n + "/bn"]
-            ops.channel_stats(a["z"], a["sums"])
-            ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
+            if self.batch_norm:
+                bn = self.params[n + "/bn"]
+                ops.channel_stats(a["z"], a["sums"])
+                ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
+            else:
+                ops.bias_relu(a["z"], self.params[n + "/biases"], a["y"])
             h = a["y"]
             if a["pool"]:
                 ops.maxpool2(a["y"], a["pooled"])
@@ -337,8 +349,11 @@ class VGG16Model:
                 ops.maxpool2_bwd(a["y"], a["pooled"], g, dy)
                 g = dy
             dz = self._buf(("dz", a["z"].shape), a["z"])
-            bn = self.params[n + "/bn"]
-            ops.bn_relu_bwd(g, a["y"], a["z"], a["sums"], bn[1], self.grads[n + "/bn"], dz, self.epsilon)
+            if self.batch_norm:
+                bn = self.params[n + "/bn"]
+                ops.bn_relu_bwd(g, a["y"], a["z"], a["sums"], bn[1], self.grads[n + "/bn"], dz, self.epsilon)
+            else:
+                ops.bias_relu_bwd(g, a["y"], dz, self.grads[n + "/biases"])
             if i == 0:
                 ops.conv3x3_small_wgrad(self._x, dz, self.grads[n + "/weights"])
             else:

@@ -189,3 +189,36 @@ def rmsprop_step(param, grad, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0):
     assert _chk(grad, F32, "grad").numel() == n and _chk(ms, F32, "ms").numel() == n
     _call("slamhip_rmsprop_step", capi.ptr(param), capi.ptr(grad), capi.ptr(ms), n, float(lr), float(decay),
           float(eps), float(grad_scale))
+
+
+def weighted_sq_loss(out, gt, loss_weight, scale, loss, d_out=None):
+    """loss = scale * sum(((out - gt) W)^2); scale 1/B is the LSTM trainer's loss (lstm_model.py:52-55)."""
+    B, D = _chk(out, F32, "out").shape
+    assert _chk(gt, F32, "gt").shape == (B, D) and _chk(loss_weight, F32, "loss_weight").shape == (D, D)
+    assert _chk(loss, F32, "loss").numel() == 1 and D <= 8
+    if d_out is not None:
+        assert _chk(d_out, F32, "d_out").shape == (B, D)
+    _call("slamhip_weighted_sq_loss", capi.ptr(out), capi.ptr(gt), capi.ptr(loss_weight), float(scale), capi.ptr(loss),
+          capi.ptr(d_out), B, D)
+
+
+def posenet_loss(out7, gt7, loss, d_out=None, beta=1100.0):
+    """vgg16_posenet.py:16-25."""
+    B, D = _chk(out7, F32, "out").shape
+    assert D == 7 and _chk(gt7, F32, "gt").shape == (B, 7) and _chk(loss, F32, "loss").numel() == 1
+    if d_out is not None:
+        assert _chk(d_out, F32, "d_out").shape == (B, 7)
+    _call("slamhip_posenet_loss", capi.ptr(out7), capi.ptr(gt7), float(beta), capi.ptr(loss), capi.ptr(d_out), B)
+
+
+def bias_relu(z, bias, y):
+    C = _chk(z, BF16, "z").shape[-1]
+    assert _chk(y, BF16, "y").shape == z.shape and _chk(bias, F32, "bias").shape == (C,) and C % 8 == 0
+    _call("slamhip_bias_relu_fwd", capi.ptr(z), capi.ptr(bias), capi.ptr(y), z.numel() // C, C)
+
+
+def bias_relu_bwd(dy, y, dz, dbias):
+    C = _chk(y, BF16, "y").shape[-1]
+    assert _chk(dy, BF16, "dy").shape == y.shape and _chk(dz, BF16, "dz").shape == y.shape
+    assert _chk(dbias, F32, "dbias").shape == (C,) and C % 64 == 0
+    _call("slamhip_bias_relu_bwd", capi.ptr(dy), capi.ptr(y), capi.ptr(dz), capi.ptr(dbias), y.numel() // C, C)

@@ -166,7 +166,7 @@ def test_backward_layer_by_layer(small_model):
         top = F.max_pool2d(y, 2) if pool else y     # the pool picks among the stored bfloat16 values
         top.backward(cpu(trace[name]["g_out"]).permute(0, 3, 1, 2))
         assert rel_l2(model.grads[name + "/bn"], bn.grad) < 1e-2, name
-        assert rel_l2(trace[name]["dz"].permute(0, 3, 1, 2), z.grad) < 1e-2, name   # stored as bfloat16
+        assert rel_l2(trace[name]["dz"].permute(0, 3, 1, 2), z.grad) < 2e-2, name   # stored as bfloat16; rare ReLU-gate flips
         # (b) convolution backward from the dz the GPU stored.  (Against the unrounded dz the
         #     filter gradient is a few percent off: sum(dz) = 0 per channel cancels the large
         #     mean of the post-ReLU input, and bfloat16 rounding of dz breaks that cancellation.)
@@ -221,3 +221,29 @@ def test_zero_loss_weight_gives_zero_gradients(small_model):
     assert float(model.loss) == 0.0
     assert float(model.flat_grads.abs().max()) == 0.0
     model._loss_weight.copy_(torch.eye(6))
+
+
+def test_no_batch_norm_variant_trains():
+    """cnn_model_noBN.VGG16Model: conv -> bias -> ReLU; gradients against autograd on the
+    output layer's input chain are covered per operator, here the wiring: parameter table,
+    finite loss, descent."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slam_amd.network.cnn_model_noBN import VGG16Model
+    B = 2
+    g = torch.Generator().manual_seed(5)
+    x = (0.5 * torch.randn(B, 32, 32, 4, generator=g)).cuda()
+    model = VGG16Model(B, x, 6, fc_dim=128, seed=2)
+    model.build_graph()
+    assert "conv3_2/biases" in model.params and "conv3_2/bn" not in model.params
+    model.add_loss(torch.eye(6).cuda(), torch.zeros(B, 6).cuda())
+    step = model.add_optimizer()
+    model._optimizer.learning_rate = 1e-4
+    # first-layer check against float32: conv + bias + relu
+    model.forward()
+    w, b = model.params["conv1_1/weights"].cpu(), model.params["conv1_1/biases"].cpu()
+    xq = x.cpu().to(torch.bfloat16).float().permute(0, 3, 1, 2)
+    want = torch.relu(F.conv2d(xq, w.permute(3, 2, 0, 1), padding=1).to(torch.bfloat16).float() + b.view(1, -1, 1, 1))
+    assert rel_l2(model._act[0]["y"].permute(0, 3, 1, 2), want) < 5e-3
+    losses = [float(step()) for _ in range(6)]
+    assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -217,3 +217,42 @@ def test_bias_act_loss_adam_casts(ops):
     dst2 = torch.empty(37, 70, dtype=BF, device="cuda")
     ops.cast_bf16(src.cuda(), dst2)
     assert torch.equal(dst2.float().cpu(), src)
+
+
+def test_alternative_losses_against_the_oracle(ops):
+    from oracle import slam_oracle as so
+    from slam_amd.network import losses
+    B = 5
+    out, gt, Wl = rnd(B, 6, seed=30), rnd(B, 6, seed=31), rnd(6, 6, seed=32)
+    loss, d = losses.lstm_loss(out.cuda(), gt.cuda(), Wl.cuda())
+    assert abs(float(loss) - so.lstm_loss(out.numpy(), gt.numpy(), Wl.numpy())) <= 1e-5 * abs(float(loss))
+    o = out.clone().requires_grad_()
+    ((((o - gt) @ Wl) ** 2).sum() / B).backward()
+    close(d, o.grad, rtol=1e-4)
+    out7, gt7 = rnd(B, 7, seed=33), rnd(B, 7, seed=34)
+    loss, d = losses.posenet_loss(out7.cuda(), gt7.cuda())
+    want = so.posenet_loss(out7.numpy(), gt7.numpy())
+    assert abs(float(loss) - want) <= 1e-5 * abs(want)
+    o = out7.clone().requires_grad_()
+    (((o[:, :3] - gt7[:, :3]) ** 2).sum() + 1100 * ((o[:, 3:] - gt7[:, 3:]) ** 2).sum()).backward()
+    close(d, o.grad, rtol=1e-5)
+    total, grads = losses.posenet_multi_head_loss([out7.cuda()] * 3, gt7.cuda())
+    assert abs(float(total) - 1.6 * want) <= 1e-4 * abs(want)
+
+
+@pytest.mark.parametrize("shape,C", [((2, 5, 6), 64), ((1, 3, 3), 256)])
+def test_bias_relu_layer(ops, shape, C):
+    z = rnd(*shape, C, seed=35).requires_grad_()
+    b = rnd(C, seed=36).requires_grad_()
+    y = torch.relu(z + b)
+    dy = rnd(*shape, C, seed=37)
+    y.backward(dy)
+    zd = z.detach().cuda().to(BF)
+    yd = torch.empty_like(zd)
+    ops.bias_relu(zd, b.detach().cuda(), yd)
+    close(yd, y)
+    dz = torch.empty_like(zd)
+    db = torch.full((C,), 3.0, device="cuda")
+    ops.bias_relu_bwd(dy.cuda().to(BF), yd, dz, db)
+    close(dz, z.grad)
+    close(db, b.grad, rtol=5e-3)
