@@ -175,6 +175,14 @@ def main():
             got_c = counts[:n].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
             verified = bool(np.array_equal(got_c, o_c.astype(np.int64)) and
                             np.allclose(sums[:n].cpu().numpy(), o_s, rtol=1e-4))
+        # HBM bytes per launch from the PMC counters: measured with tools/pmc_traffic.sh (separate
+        # rocprofv3 --pmc passes, gfx950 corrections applied) for this same workload and committed;
+        # reported only when the workload matches the one it was measured on
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r1_traffic_fused.json")
+        if os.path.exists(tpath) and B == 64 and a.factor == 1.0 and a.depth == "plane":
+            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r1_traffic_fused.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean of 110 launches)"
         pairs = world * B * a.steps
         achieved = BYTES_PER_PAIR * B / (launch_ms * 1e-3) / 1e9
         line = {
@@ -195,7 +203,8 @@ def main():
                                    % (B, a.depth, a.factor),
                        "pairs_per_gpu_per_step": B, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                         "traffic_source": traffic_src,
                          "kernel": "pair_loss_fused_kernel", "launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": BYTES_PER_PAIR * B},
             "cpu_baseline": cb,
