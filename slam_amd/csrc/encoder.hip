@@ -335,53 +335,149 @@ conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ 
   atomicAdd(&dW[(t * Cin + ci) * Cout + co], acc);
 }
 
-// Specialisation for the network's actual first layer (4 input channels, 64 filters):
-// lane = output channel, a wave walks a run of pixels.  The 36 inputs of a pixel are the
-// same for all lanes, so they come through the scalar cache; each lane keeps its filter
-// column (forward) or its 36 partial sums (filter gradient) in registers.
-__device__ __forceinline__ void unpack4(uint2 v, float* f) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+// Specialisation for the network's actual first layer (4 input channels, 64 filters) on the
+// matrix cores: the im2col row of a pixel (9 taps x 4 channels = 36 values, padded to 64) is
+// built in LDS from nine 8-byte loads, so the layer is a [pixels x 64] x [64 x 64] product
+// (forward) or its transpose (filter gradient) and runs at memory speed.
+__device__ __forceinline__ uint2 and2(uint2 v, uint32_t keep) { return make_uint2(v.x & keep, v.y & keep); }
+
+// forward: 128 pixels x 64 filters per workgroup, one K-step
+__global__ void __launch_bounds__(256)
+conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, bf16* __restrict__ out, int P,
+                          int H, int W) {
+  __shared__ __attribute__((aligned(16))) bf16 As[128 * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[64 * LDS_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int m0 = blockIdx.x * 128;
+  // B[n][k] = filter[k][n] (k = tap * 4 + channel), zero for k >= 36
+  {
+    const int n = tid & 63, kg = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = kg * 16 + i;
+      Bs[n * LDS_PITCH + k] = (bf16)(k < 36 ? Wt[k * 64 + n] : 0.0f);
+    }
+  }
+  // A[pixel][k]: thread -> pixel tid>>1; half 0 fills taps 0..4, half 1 taps 5..8 and the zero tail
+  {
+    const int row = tid >> 1, half = tid & 1;
+    const bool row_ok = m0 + row < P;
+    const int pm = row_ok ? m0 + row : P - 1;
+    const int rem = pm % (H * W), y = rem / W, x = rem - y * W;
+    const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
+    uint2* dst = reinterpret_cast<uint2*>(&As[row * LDS_PITCH]);
+    uint2 v[5];
+    uint32_t keep[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      const int t = half * 5 + i;             // taps 0..4 | 5..9 (9 does not exist)
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = row_ok && t < 9 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
+      v[i] = Xp[ok ? pm + dy * W + dx : pm];
+      keep[i] = ok ? 0xffffffffu : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) dst[half * 5 + i] = and2(v[i], keep[i]);   // k = 4 * tap ... (tap 9 = zeros)
+    if (half) {
+#pragma unroll
+      for (int i = 10; i < 16; ++i) dst[i] = make_uint2(0u, 0u);           // k = 40..63
+    }
+  }
+  __syncthreads();
+  f32x16 acc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+  for (int kk = 0; kk < 48; kk += 16) {   // k >= 48 is all zeros
+    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (m < P) out[(long long)m * 64 + wn * 32 + (lane & 31)] = (bf16)acc[i][r];
+    }
 }
 
-template <bool WGRAD>
+// filter gradient: dW[k][n] += sum_p A[p][k] dY[p][n] over a slice of the pixels
 __global__ void __launch_bounds__(256)
-conv3x3_c4_k64_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, const bf16* __restrict__ dY,
-                      bf16* __restrict__ out, float* __restrict__ dW, int P, int H, int W, int px_per_wave) {
-  const int co = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-  const long long p0l = (long long)wave * px_per_wave;
-  if (p0l >= P) return;
-  const int p0 = (int)p0l, p1 = min(P, p0 + px_per_wave);
-  float w[36];
+conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P,
+                            int H, int W, int px_per_block) {
+  constexpr int PX = 64 + 32;   // conflict-free pitch of the transposing reads (see wgrad_bf16_kernel)
+  __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PX];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long long p_begin_l = (long long)blockIdx.x * px_per_block;
+  if (p_begin_l >= P) return;
+  const int p_begin = (int)p_begin_l, p_end = min(P, p_begin + px_per_block);
+  const int l_row = tid >> 2, l_q = tid & 3;   // pixel of the 64-pixel step, quarter of its row
+  const uint2* Xp = reinterpret_cast<const uint2*>(X);
+  const int hw = H * W;
+  f32x16 acc;
 #pragma unroll
-  for (int k = 0; k < 36; ++k) w[k] = WGRAD ? 0.0f : Wt[k * 64 + co];
-  int rem = p0 % (H * W);
-  int y = rem / W, x = rem - y * W;
-  const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
-  for (int p = p0; p < p1; ++p) {
-    float acc = 0.0f, g = 0.0f;
-    if (WGRAD) g = (float)dY[(long long)p * 64 + co];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;   // wave-uniform
-      uint2 v = make_uint2(0u, 0u);
-      if (ok) v = Xp[p + dy * W + dx];
-      float f[4];
-      unpack4(v, f);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        if (WGRAD) w[t * 4 + c] = __builtin_fmaf(f[c], g, w[t * 4 + c]);
-        else acc = __builtin_fmaf(f[c], w[t * 4 + c], acc);
-      }
-    }
-    if (!WGRAD) out[(long long)p * 64 + co] = (bf16)acc;
-    if (++x == W) { x = 0; if (++y == H) y = 0; }
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  uint2 xv[3];
+  uint4 yv[2];
+  uint32_t keep_x[3], keep_y = 0u;
+
+#define SLAMHIP_C4_ISSUE(p0)                                                                    \
+  {                                                                                             \
+    const int p = (p0) + l_row;                                                                 \
+    const bool in_slice = p < p_end;                                                            \
+    const int pc = in_slice ? p : p_end - 1;                                                    \
+    const int rem = pc % hw, y = rem / W, x = rem - y * W;                                      \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
+      const int t = l_q * 3 + i;                        /* quarter 3 owns no tap: zeros */      \
+      const int dy = t / 3 - 1, dx = t % 3 - 1;                                                 \
+      const bool ok = in_slice && t < 9 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W; \
+      xv[i] = Xp[ok ? pc + dy * W + dx : pc];                                                   \
+      keep_x[i] = ok ? 0xffffffffu : 0u;                                                        \
+    }                                                                                           \
+    const uint4* ys = reinterpret_cast<const uint4*>(dY + (long long)pc * 64 + l_q * 16);       \
+    yv[0] = ys[0]; yv[1] = ys[1];                                                               \
+    keep_y = in_slice ? 0xffffffffu : 0u;                                                       \
   }
-  if (WGRAD) {
+
+  SLAMHIP_C4_ISSUE(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+    __syncthreads();
+    {
+      uint2* xd = reinterpret_cast<uint2*>(&Xs[l_row * PX]);
+      // quarters 0..2 write taps 3q..3q+2 (k = 12q ... 12q+11); quarter 3 the zero tail k = 36..63
+      if (l_q < 3) {
 #pragma unroll
-    for (int k = 0; k < 36; ++k) atomicAdd(&dW[k * 64 + co], w[k]);
+        for (int i = 0; i < 3; ++i) xd[l_q * 3 + i] = and2(xv[i], keep_x[i]);
+      } else {
+#pragma unroll
+        for (int i = 9; i < 16; ++i) xd[i] = make_uint2(0u, 0u);
+      }
+      uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * PX + l_q * 16]);
+      yd[0] = and4(yv[0], keep_y); yd[1] = and4(yv[1], keep_y);
+    }
+    __syncthreads();
+    if (p0 + 64 < p_end) SLAMHIP_C4_ISSUE(p0 + 64);
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      const bf16x8 af = tr_frag<PX>(Xs, kk, wm * 32, lane);   // A[m = k-index][k = pixel]
+      const bf16x8 bf = tr_frag<PX>(Ys, kk, wn * 32, lane);   // B[k = pixel][n = filter]
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+  }
+#undef SLAMHIP_C4_ISSUE
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int k = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (k < 36) atomicAdd(&dW[k * 64 + wn * 32 + (lane & 31)], acc[r]);
   }
 }
 
@@ -849,10 +945,8 @@ int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16
   if (total == 0) return SLAMHIP_OK;
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
-    const int px_per_wave = 64, waves = (P + px_per_wave - 1) / px_per_wave;
-    hipLaunchKernelGGL(conv3x3_c4_k64_kernel<false>, dim3((waves + 3) / 4), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, w_hwio, (const bf16*)nullptr, (bf16*)out_bf16, (float*)nullptr, P, H, W,
-                       px_per_wave);
+    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3((P + 127) / 128), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, w_hwio, (bf16*)out_bf16, P, H, W);
   } else {
     hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
                        (const bf16*)x, w_hwio, (bf16*)out_bf16, P, H, W, Cin, Cout);
@@ -870,11 +964,10 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
   if (B == 0) return SLAMHIP_OK;
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
-    int px_per_wave = (P + 8191) / 8192;          // about 8192 waves, each ending in 36 atomics per lane
-    if (px_per_wave < 16) px_per_wave = 16;
-    const int waves = (P + px_per_wave - 1) / px_per_wave;
-    hipLaunchKernelGGL(conv3x3_c4_k64_kernel<true>, dim3((waves + 3) / 4), dim3(256), 0, s, (const bf16*)x,
-                       (const float*)nullptr, (const bf16*)dy, (bf16*)nullptr, dw, P, H, W, px_per_wave);
+    // about 2048 workgroups, slices in multiples of 64 pixels
+    int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
+    hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0, s,
+                       (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block);
   } else {
     hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x,
                        (const bf16*)dy, dw, P, H, W, Cin, Cout);

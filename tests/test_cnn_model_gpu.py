@@ -25,7 +25,7 @@ def torch_reference(model, x, gt, Wl, eps, storage_rounding):
     h = x.permute(0, 3, 1, 2)
     for i, (name, _, pool) in enumerate(CONV_LAYERS):
         w = P[name + "/weights"]
-        h = q(F.conv2d(h, (w if i == 0 else q(w)).permute(3, 2, 0, 1), padding=1))
+        h = q(F.conv2d(h, q(w).permute(3, 2, 0, 1), padding=1))
         mean = h.mean(dim=(0, 2, 3), keepdim=True)
         var = h.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
         bn = P[name + "/bn"]
@@ -82,7 +82,7 @@ def test_forward_layer_by_layer(small_model):
     for i, (name, _, pool) in enumerate(CONV_LAYERS):
         a = model._act[i]
         w = P[name + "/weights"]
-        z = q(F.conv2d(h, (w if i == 0 else q(w)).permute(3, 2, 0, 1), padding=1))
+        z = q(F.conv2d(h, q(w).permute(3, 2, 0, 1), padding=1))
         assert rel_l2(a["z"].permute(0, 3, 1, 2), z) < 1e-3, name
         zg = a["z"].float().cpu().permute(0, 3, 1, 2)
         mean = zg.mean(dim=(0, 2, 3), keepdim=True)
@@ -157,7 +157,7 @@ def test_backward_layer_by_layer(small_model):
         h_in = h_in.permute(0, 3, 1, 2).clone().requires_grad_()
         w = P[name + "/weights"].clone().requires_grad_()
         bn = P[name + "/bn"].clone().requires_grad_()
-        wq = (w if i == 0 else q(w)).permute(3, 2, 0, 1)
+        wq = q(w).permute(3, 2, 0, 1)
         # (a) normalisation + ReLU (+ pool) backward: dz, dbeta, dscale from the incoming gradient
         z = q(F.conv2d(h_in, wq, padding=1)).detach().requires_grad_()
         mean = z.mean(dim=(0, 2, 3), keepdim=True)
@@ -243,7 +243,7 @@ def test_no_batch_norm_variant_trains():
     model.forward()
     w, b = model.params["conv1_1/weights"].cpu(), model.params["conv1_1/biases"].cpu()
     xq = x.cpu().to(torch.bfloat16).float().permute(0, 3, 1, 2)
-    want = torch.relu(F.conv2d(xq, w.permute(3, 2, 0, 1), padding=1).to(torch.bfloat16).float() + b.view(1, -1, 1, 1))
+    want = torch.relu(F.conv2d(xq, w.to(torch.bfloat16).float().permute(3, 2, 0, 1), padding=1).to(torch.bfloat16).float() + b.view(1, -1, 1, 1))
     assert rel_l2(model._act[0]["y"].permute(0, 3, 1, 2), want) < 5e-3
     losses = [float(step()) for _ in range(6)]
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses

@@ -96,7 +96,7 @@ def test_gemm_nt_and_fc_wgrad(ops, M, N, K):
 def test_first_layer(ops):
     B, H, W, C, N = 2, 10, 12, 4, 64
     x = rnd(B, H, W, C, seed=10).requires_grad_()
-    w = rnd(3, 3, C, N, seed=11, scale=0.05).requires_grad_()
+    w = rnd(3, 3, C, N, seed=11, scale=0.05).requires_grad_()   # bfloat16-representable: the kernel rounds the filter
     y = conv_ref(x, w)
     dy = rnd(B, H, W, N, seed=12)
     y.backward(dy)
