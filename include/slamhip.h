@@ -177,13 +177,14 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
  * channel_stats: sums2c[c] = sum z, sums2c[C+c] = sum z^2 over the P rows of z
  * [P][C] bf16 (float32 [2C], overwritten).  bn_relu_fwd: y = relu(gamma *
  * (z - mean) / sqrt(var + eps) + beta) (cnn_model.py:107,113).  bn_relu_bwd: dz
- * from dy through the ReLU and the normalisation, and red2c[c] = dbeta,
+ * from dy through the ReLU (gate recomputed from z, y is not read) and the
+ * normalisation, and red2c[c] = dbeta,
  * red2c[C+c] = dgamma (float32 [2C], overwritten).  C % 64 == 0. */
 int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void* stream);
 int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta,
                         void* y, long long P, int C, float eps, void* stream);
-int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const float* sums2c,
-                        const float* gamma, float* red2c, void* dz, long long P, int C, float eps,
+int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, const float* gamma,
+                        const float* beta, float* red2c, void* dz, long long P, int C, float eps,
                         void* stream);
 
 /* cnn_model.py:123,74 / cnn_model_noBN.py (bias_add + relu) - y = act(z + bias) on a float32

@@ -494,15 +494,16 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
 template <int BWD>
 __global__ void __launch_bounds__(256)
 channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, const bf16* __restrict__ z,
-                      const float* __restrict__ sums, float* __restrict__ out, int P, int C, float inv_count,
+                      const float* __restrict__ sums, const float* __restrict__ gamma,
+                      const float* __restrict__ beta, float* __restrict__ out, int P, int C, float inv_count,
                       float eps) {
   __shared__ float part[256 * 17];
   const int groups = C >> 3;                      // <= 256 (checked on the host)
   const int rlanes = 256 / groups;
   const int gcol = threadIdx.x % groups, rlane = threadIdx.x / groups;
-  float s0[8], s1[8], mean[8], rstd[8];
+  float s0[8], s1[8], mean[8], rstd[8], gam[8], bet[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 0.f; gam[j] = 0.f; bet[j] = 0.f; }
   if (rlane < rlanes) {
     if (BWD == 1) {
 #pragma unroll
@@ -510,6 +511,8 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
         const int c = gcol * 8 + j;
         mean[j] = sums[c] * inv_count;
         rstd[j] = rsqrtf(fmaxf(sums[C + c] * inv_count - mean[j] * mean[j], 0.0f) + eps);
+        gam[j] = gamma[c] * rstd[j];     // the forward pass's scale, same operations
+        bet[j] = beta[c];
       }
     }
     const int stride = gridDim.x * rlanes;
@@ -517,12 +520,14 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
       const long long o = ((long long)p * C >> 3) + gcol;
       const bf16x8 va = reinterpret_cast<const bf16x8*>(a)[o];
       if (BWD == 1) {
-        const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[o], vz = reinterpret_cast<const bf16x8*>(z)[o];
+        // the ReLU gate is recomputed from z exactly as the forward pass computed y: y is not read
+        const bf16x8 vz = reinterpret_cast<const bf16x8*>(z)[o];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float g = ((float)vy[j] > 0.0f) ? (float)va[j] : 0.0f;
+          const float d = (float)vz[j] - mean[j];
+          const float g = (__builtin_fmaf(d, gam[j], bet[j]) > 0.0f) ? (float)va[j] : 0.0f;
           s0[j] += g;
-          s1[j] = __builtin_fmaf(g, ((float)vz[j] - mean[j]) * rstd[j], s1[j]);
+          s1[j] = __builtin_fmaf(g, d * rstd[j], s1[j]);
         }
       } else if (BWD == 2) {
         const bf16x8 vy = reinterpret_cast<const bf16x8*>(y)[o];
@@ -573,15 +578,14 @@ bn_relu_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ sums, c
 
 // dz = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat))
 __global__ void __launch_bounds__(256)
-bn_relu_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y, const bf16* __restrict__ z,
+bn_relu_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ z,
                          const float* __restrict__ sums, const float* __restrict__ red,
-                         const float* __restrict__ gamma, bf16* __restrict__ dz, long long total8, int C,
-                         float inv_count, float eps) {
+                         const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ dz,
+                         long long total8, int C, float inv_count, float eps) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total8) return;
   const int c0 = (int)((i * 8) % C);
-  const bf16x8 vdy = reinterpret_cast<const bf16x8*>(dy)[i], vy = reinterpret_cast<const bf16x8*>(y)[i],
-               vz = reinterpret_cast<const bf16x8*>(z)[i];
+  const bf16x8 vdy = reinterpret_cast<const bf16x8*>(dy)[i], vz = reinterpret_cast<const bf16x8*>(z)[i];
   bf16x8 o;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -589,9 +593,11 @@ bn_relu_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ y
     const float mean = sums[c] * inv_count;
     const float var = fmaxf(sums[C + c] * inv_count - mean * mean, 0.0f);
     const float rstd = rsqrtf(var + eps);
-    const float xhat = ((float)vz[j] - mean) * rstd;
-    const float g = ((float)vy[j] > 0.0f) ? (float)vdy[j] : 0.0f;
-    o[j] = (bf16)(gamma[c] * rstd * (g - red[c] * inv_count - xhat * red[C + c] * inv_count));
+    const float d = (float)vz[j] - mean;
+    const float r = gamma[c] * rstd;
+    const float xhat = d * rstd;
+    const float g = (__builtin_fmaf(d, r, beta[c]) > 0.0f) ? (float)vdy[j] : 0.0f;   // forward's y > 0
+    o[j] = (bf16)(r * (g - red[c] * inv_count - xhat * red[C + c] * inv_count));
   }
   reinterpret_cast<bf16x8*>(dz)[i] = o;
 }
@@ -984,7 +990,8 @@ int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "channel_stats: more than 2048 channels");
   hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)z,
-                     (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr, sums2c, (int)P, C, 0.0f, 0.0f);
+                     (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, sums2c, (int)P, C, 0.0f, 0.0f);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -1000,19 +1007,19 @@ int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, 
   return SLAMHIP_OK;
 }
 
-int slamhip_bn_relu_bwd(const void* dy, const void* y, const void* z, const float* sums2c, const float* gamma,
+int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, const float* gamma, const float* beta,
                         float* red2c, void* dz, long long P, int C, float eps, void* stream) {
-  SLAMHIP_REQUIRE(dy && y && z && sums2c && gamma && red2c && dz && P > 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG,
+  SLAMHIP_REQUIRE(dy && z && sums2c && gamma && beta && red2c && dz && P > 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG,
                   "bn_relu_bwd: bad argument");
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_bwd: too many rows");
+  SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
   hipStream_t s = (hipStream_t)stream;
   SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
-  SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
   hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)y, (const bf16*)z, sums2c, red2c, (int)P, C, 1.0f / (float)P, eps);
+                     (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)y, (const bf16*)z, sums2c, red2c, gamma, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+                     (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -1127,7 +1134,8 @@ int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias,
   SLAMHIP_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s));
   if (P == 0) return SLAMHIP_OK;
   hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)y, (const bf16*)nullptr, (const float*)nullptr, dbias, (int)P, C, 0.0f, 0.0f);
+                     (const bf16*)y, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, dbias, (int)P, C, 0.0f, 0.0f);
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(relu_gate_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
                      (bf16*)dz, total8);

@@ -351,7 +351,7 @@ class VGG16Model:
             dz = self._buf(("dz", a["z"].shape), a["z"])
             if self.batch_norm:
                 bn = self.params[n + "/bn"]
-                ops.bn_relu_bwd(g, a["y"], a["z"], a["sums"], bn[1], self.grads[n + "/bn"], dz, self.epsilon)
+                ops.bn_relu_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
             else:
                 ops.bias_relu_bwd(g, a["y"], dz, self.grads[n + "/biases"])
             if i == 0:

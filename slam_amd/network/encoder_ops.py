@@ -108,14 +108,15 @@ def bn_relu(z, sums2c, gamma, beta, y, eps):
           float(eps))
 
 
-def bn_relu_bwd(dy, y, z, sums2c, gamma, red2c, dz, eps):
-    """dz, and red2c[0] = dbeta, red2c[1] = dgamma."""
+def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps):
+    """dz, and red2c[0] = dbeta, red2c[1] = dgamma.  The ReLU gate is recomputed from z."""
     C = _chk(z, BF16, "z").shape[-1]
     P = z.numel() // C
-    for t in (dy, y, dz):
+    for t in (dy, dz):
         assert _chk(t, BF16, "bn tensor").shape == z.shape
-    assert _chk(red2c, F32, "red").shape == (2, C) and sums2c.shape == (2, C) and gamma.shape == (C,)
-    _call("slamhip_bn_relu_bwd", capi.ptr(dy), capi.ptr(y), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma),
+    assert _chk(red2c, F32, "red").shape == (2, C) and sums2c.shape == (2, C)
+    assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
+    _call("slamhip_bn_relu_bwd", capi.ptr(dy), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta),
           capi.ptr(red2c), capi.ptr(dz), P, C, float(eps))
 
 

@@ -134,7 +134,7 @@ def test_batchnorm_relu(ops, P_shape, C):
     # through the same rounding by using yd as produced above
     red = torch.empty(2, C, dtype=torch.float32, device=dev)
     dz = torch.empty_like(zd)
-    ops.bn_relu_bwd(dy.to(dev).to(BF), yd, zd, sums, gamma.detach().to(dev), red, dz, eps)
+    ops.bn_relu_bwd(dy.to(dev).to(BF), zd, sums, gamma.detach().to(dev), beta.detach().to(dev), red, dz, eps)
     close(red[0], beta.grad, rtol=5e-3)
     close(red[1], gamma.grad, rtol=5e-3)
     close(dz, z.grad, rtol=2e-2)
