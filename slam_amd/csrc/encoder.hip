@@ -234,6 +234,16 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
   const bf16* x_col = X + ci0 + l_q * (TM / 4);
   const bf16* y_col = dY + co0 + l_q * (TN / 4);
 
+  // Pixel coordinates advance with the steps: (y0, x0) belongs to the step's first pixel and a
+  // lane adds its row; floor(x / W) for x < W + 64 is a compare (W >= 64) or one multiply by
+  // a 20-bit reciprocal (exact while x * W < 2^20, here x < 128).
+  const unsigned int magic_w = ((1u << 20) + (unsigned int)W - 1u) / (unsigned int)W;
+  int y0 = 0, x0 = 0;
+  if (TAPS == 9) {
+    const int rem0 = p_begin % hw;
+    y0 = rem0 / W;
+    x0 = rem0 - y0 * W;
+  }
 #define SLAMHIP_WGRAD_ISSUE(p0)                                                                     \
   {                                                                                                 \
     const int p = (p0) + l_row;                                                                     \
@@ -242,7 +252,11 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
     long long xo = (long long)pc * Cin;                                                             \
     bool x_ok = in_slice;                                                                           \
     if (TAPS == 9) {                                                                                \
-      const int rem = pc % hw, y = rem / W, x = rem - y * W;                                        \
+      int x = x0 + l_row;                                                                           \
+      const int q = (W >= 64) ? (x >= W ? 1 : 0) : (int)(((unsigned int)x * magic_w) >> 20);        \
+      x -= q * W;                                                                                   \
+      int y = y0 + q;                                                                               \
+      while (y >= H) y -= H;                                                                        \
       x_ok = in_slice && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;      \
       if (x_ok) xo += (long long)(dy * W + dx) * Cin;                                               \
     }                                                                                               \
@@ -252,6 +266,13 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
     _Pragma("unroll") for (int i = 0; i < YV; ++i) ry[i] = ys[i];                                   \
     keep_x = x_ok ? 0xffffffffu : 0u;                                                               \
     keep_y = in_slice ? 0xffffffffu : 0u;                                                           \
+    if (TAPS == 9) {                                                                                \
+      x0 += 64;                                                                                     \
+      const int q0 = (W >= 64) ? (x0 >= W ? 1 : 0) : (int)(((unsigned int)x0 * magic_w) >> 20);     \
+      x0 -= q0 * W;                                                                                 \
+      y0 += q0;                                                                                     \
+      while (y0 >= H) y0 -= H;                                                                      \
+    }                                                                                               \
   }
 
   if (p_begin < p_end) SLAMHIP_WGRAD_ISSUE(p_begin);
@@ -556,50 +577,68 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
   }
 }
 
+// Both element-wise batch-norm kernels walk the tensor with a stride that is a multiple of C
+// (the host picks the grid), so a thread meets the same 8 channels in every iteration and
+// keeps their coefficients in registers.
 // y = relu(gamma * (z - mean) * rsqrt(var + eps) + beta), 8 channels per thread
 __global__ void __launch_bounds__(256)
 bn_relu_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ sums, const float* __restrict__ gamma,
                    const float* __restrict__ beta, bf16* __restrict__ y, long long total8, int C, float inv_count,
                    float eps) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total8) return;
   const int c0 = (int)((i * 8) % C);
-  const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
-  bf16x8 o;
+  float mean[8], r[8], bet[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const float mean = sums[c0 + j] * inv_count;
-    const float var = fmaxf(sums[C + c0 + j] * inv_count - mean * mean, 0.0f);
-    const float r = gamma[c0 + j] * rsqrtf(var + eps);
-    o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[j] - mean, r, beta[c0 + j]), 0.0f);
+    mean[j] = sums[c0 + j] * inv_count;
+    const float var = fmaxf(sums[C + c0 + j] * inv_count - mean[j] * mean[j], 0.0f);
+    r[j] = gamma[c0 + j] * rsqrtf(var + eps);
+    bet[j] = beta[c0 + j];
   }
-  reinterpret_cast<bf16x8*>(y)[i] = o;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total8; i += stride) {
+    const bf16x8 v = reinterpret_cast<const bf16x8*>(z)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[j] - mean[j], r[j], bet[j]), 0.0f);
+    reinterpret_cast<bf16x8*>(y)[i] = o;
+  }
 }
 
-// dz = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat))
+// dz = gamma * rstd * (dyr - mean(dyr) - xhat * mean(dyr * xhat)), dyr = dy gated by the forward's y > 0
 __global__ void __launch_bounds__(256)
 bn_relu_bwd_apply_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ z,
                          const float* __restrict__ sums, const float* __restrict__ red,
                          const float* __restrict__ gamma, const float* __restrict__ beta, bf16* __restrict__ dz,
                          long long total8, int C, float inv_count, float eps) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total8) return;
   const int c0 = (int)((i * 8) % C);
-  const bf16x8 vdy = reinterpret_cast<const bf16x8*>(dy)[i], vz = reinterpret_cast<const bf16x8*>(z)[i];
-  bf16x8 o;
+  float mean[8], r[8], bet[8], k1[8], k2[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int c = c0 + j;
-    const float mean = sums[c] * inv_count;
-    const float var = fmaxf(sums[C + c] * inv_count - mean * mean, 0.0f);
+    mean[j] = sums[c] * inv_count;
+    const float var = fmaxf(sums[C + c] * inv_count - mean[j] * mean[j], 0.0f);
     const float rstd = rsqrtf(var + eps);
-    const float d = (float)vz[j] - mean;
-    const float r = gamma[c] * rstd;
-    const float xhat = d * rstd;
-    const float g = (__builtin_fmaf(d, r, beta[c]) > 0.0f) ? (float)vdy[j] : 0.0f;   // forward's y > 0
-    o[j] = (bf16)(r * (g - red[c] * inv_count - xhat * red[C + c] * inv_count));
+    r[j] = gamma[c] * rstd;
+    bet[j] = beta[c];
+    k1[j] = red[c] * inv_count;
+    k2[j] = rstd * (red[C + c] * inv_count);
   }
-  reinterpret_cast<bf16x8*>(dz)[i] = o;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total8; i += stride) {
+    const bf16x8 vdy = reinterpret_cast<const bf16x8*>(dy)[i], vz = reinterpret_cast<const bf16x8*>(z)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float d = (float)vz[j] - mean[j];
+      const float g = (__builtin_fmaf(d, r[j], bet[j]) > 0.0f) ? (float)vdy[j] : 0.0f;   // forward's y > 0
+      o[j] = (bf16)(r[j] * ((g - k1[j]) - d * k2[j]));
+    }
+    reinterpret_cast<bf16x8*>(dz)[i] = o;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -844,6 +883,18 @@ rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __rest
 static unsigned int blocks_for(long long n, int per = 256) { return (unsigned int)((n + per - 1) / per); }
 
 
+// Grid of 256-thread blocks for a grid-stride walk over total8 8-channel vectors in which every
+// thread keeps the same channels: blocks * 256 * 8 elements must be a multiple of C.
+static unsigned int channel_stride_grid(long long total8, int C) {
+  long long a = C, b = 2048;
+  while (b) { const long long t = a % b; a = b; b = t; }      // a = gcd(C, 2048)
+  const long long unit = C / a;                                // blocks per period
+  long long g = (total8 + 255) / 256;
+  if (g > 4096) g = 4096;
+  g = g / unit * unit;
+  return (unsigned int)(g < unit ? unit : g);
+}
+
 // rows are strided over the grid: enough blocks to fill the chip, at least ~8 rows per row lane
 static unsigned int reduce_grid(long long P, int C) {
   const int rlanes = 256 / (C / 8);
@@ -1001,8 +1052,8 @@ int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, 
   SLAMHIP_REQUIRE(z && sums2c && gamma && beta && y && P > 0 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG,
                   "bn_relu_fwd: bad argument");
   const long long total8 = P * C / 8;
-  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(blocks_for(total8)), dim3(256), 0, (hipStream_t)stream, (const bf16*)z,
-                     sums2c, gamma, beta, (bf16*)y, total8, C, 1.0f / (float)P, eps);
+  hipLaunchKernelGGL(bn_relu_fwd_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)z, sums2c, gamma, beta, (bf16*)y, total8, C, 1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -1018,7 +1069,7 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
   hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
   const long long total8 = P * C / 8;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy,
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
