@@ -42,12 +42,14 @@ METRIC = "RGB-D frame pairs/sec @640×480 (warp+loss+encoder), 1/2/4/8 GPU, % HB
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per GPU per step")
     ap.add_argument("--buffers", type=int, default=4, help="distinct HBM batches the steps rotate through")
     ap.add_argument("--factor", type=float, default=1.0, help="depth divisor (1 = reference, 5000 = metric)")
     ap.add_argument("--depth", default="plane", choices=["plane", "noise"])
+    ap.add_argument("--size", default="480x640", help="frame size HxW (960x1280 = the high-resolution configuration)")
+    ap.add_argument("--neighbours", type=int, default=1, help="neighbour frames warped per anchor (k)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline (0 = skip)")
     ap.add_argument("--encoder-steps", type=int, default=3,
                     help="training steps of the pose-regression encoder timed after the headline "
@@ -64,12 +66,12 @@ def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s):
     done, t0 = 0, time.perf_counter()
     while True:
         sums, counts = c_oracle.pair_loss(*args)
-        done += n
+        done += n * rel.shape[1]
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
     return dict(value=done / el, unit="frame pairs/s", cores=1, kind="port",
-                sample="%d pairs (the first %d pairs of rank 0's batch, repeated) in %.1f s, "
+                sample="%d pairs (the first %d anchors of rank 0's batch, repeated) in %.1f s, "
                        "oracle/slam_oracle.c single-threaded" % (done, n, el)), sums, counts
 
 
@@ -92,18 +94,20 @@ def main():
     from slam_amd import frame_pairs as fp
     from slam_amd.utils import synthetic as syn
 
-    B = a.batch
-    K = fp.intrinsics(1)
+    B, k = a.batch, a.neighbours
+    H, W = [int(v) for v in a.size.lower().split("x")]
+    K = tuple(v * W / 640.0 for v in fp.intrinsics(1))
+    bytes_per_launch = B * H * W * 5 * (1 + k)          # anchor read once, k neighbours
     seed = 1000 * rank
-    gt = syn.pose_pairs(B, seed=seed + 3)
+    gt = syn.pose_pairs(B * k, seed=seed + 3)
     d1 = syn.depth_frames(B, H, W, seed=seed + 1, kind=a.depth)
-    d2 = syn.depth_frames(B, H, W, seed=seed + 2, kind=a.depth)
+    d2 = syn.depth_frames(B * k, H, W, seed=seed + 2, kind=a.depth).reshape(B, k, H, W)
     c1 = syn.rgb_frames(B, H, W, seed=seed + 1, kind="noise")
-    c2 = syn.rgb_frames(B, H, W, seed=seed + 2, kind="noise")
+    c2 = syn.rgb_frames(B * k, H, W, seed=seed + 2, kind="noise").reshape(B, k, H, W, 3)
 
     dev = torch.device("cuda", torch.cuda.current_device())
     gt_d = torch.from_numpy(gt).to(dev)
-    rel = fp.relative_pose(gt_d[:, 0].contiguous(), gt_d[:, 1].contiguous()).reshape(B, 1, 4, 4)
+    rel = fp.relative_pose(gt_d[:, 0].contiguous(), gt_d[:, 1].contiguous()).reshape(B, k, 4, 4)
     bufs = []
     for i in range(max(1, a.buffers)):
         # the same pairs in a rotated order, each copy in its own HBM allocation
@@ -180,11 +184,11 @@ def main():
         # reported only when the workload matches the one it was measured on
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r1_traffic_fused.json")
-        if os.path.exists(tpath) and B == 64 and a.factor == 1.0 and a.depth == "plane":
+        if os.path.exists(tpath) and (B, k, H, W) == (64, 1, 480, 640) and a.factor == 1.0 and a.depth == "plane":
             traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
             traffic_src = "profiles/r1_traffic_fused.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean of 110 launches)"
-        pairs = world * B * a.steps
-        achieved = BYTES_PER_PAIR * B / (launch_ms * 1e-3) / 1e9
+        pairs = world * B * k * a.steps
+        achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         line = {
             "metric": METRIC,
             "value": pairs / elapsed,
@@ -198,15 +202,16 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic 640x480 depth+RGB pairs, batch %d per GPU, "
-                                   "backproject+warp+loss fused (k=1 neighbour), %s depth, factor %g"
-                                   % (B, a.depth, a.factor),
-                       "pairs_per_gpu_per_step": B, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world},
+            "config": {"workload": "%ssynthetic %dx%d depth+RGB pairs, batch %d anchors per GPU, "
+                                   "backproject+warp+loss fused (k=%d neighbour%s), %s depth, factor %g"
+                                   % ("configs[1]: " if (k, H, W) == (1, 480, 640) else "", W, H, B, k,
+                                      "" if k == 1 else "s", a.depth, a.factor),
+                       "pairs_per_gpu_per_step": B * k, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
                          "kernel": "pair_loss_fused_kernel", "launch_ms": launch_ms,
-                         "algorithmic_bytes_per_launch": BYTES_PER_PAIR * B},
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cb,
             "verified_against_oracle": verified,
             "encoder": encoder,

@@ -263,3 +263,27 @@ def test_fused_equals_materialised_at_bench_size(fp):
     assert np.array_equal(_u32(counts)[:, 0], cnt)
     np.testing.assert_allclose(sums.cpu().numpy()[:, 0], ref, rtol=1e-5)
     assert (cnt[:, 2] > 0.5 * 480 * 640).all()  # TUM-like motion keeps most pixels in view
+
+
+def test_high_res_four_neighbours(fp):
+    """1280x960 frames, k = 4 neighbours per anchor, intrinsics doubled (the high-resolution
+    configuration): counts and sums of the fused kernel against the materialised per-pixel
+    outputs for every neighbour, and neighbour 2 of anchor 0 against the C oracle."""
+    from oracle import c_oracle
+    H, W, B, k = 960, 1280, 2, 4
+    K = tuple(2.0 * v for v in fp.intrinsics(1))
+    d1, c1, d2, c2, rel = _pairs(B, k, H, W, seed=77, depth_kind="plane", rgb_kind="smooth")
+    D1, C1, D2, C2, R = _dev(d1), _dev(c1), _dev(d2), _dev(c2), _dev(rel)
+    sums, counts = fp.pair_loss(D1, C1, D2, C2, R, K, 1.0)
+    o = fp.warp(D1, C1, D2, C2, R, K, 1.0)
+    got_c = _u32(counts)
+    for q in range(4):
+        want = ((o["mask"] >> q) & 1).sum(dim=(2, 3)).cpu().numpy()
+        assert np.array_equal(got_c[..., q], want)
+    rp, rg = o["r_photo"].double(), o["r_geo"].double()
+    ref = np.stack([rp.abs().sum(dim=(2, 3, 4)).cpu().numpy(), (rp * rp).sum(dim=(2, 3, 4)).cpu().numpy(),
+                    rg.abs().sum(dim=(2, 3)).cpu().numpy(), (rg * rg).sum(dim=(2, 3)).cpu().numpy()], axis=-1)
+    np.testing.assert_allclose(sums.cpu().numpy(), ref, rtol=RTOL)
+    s_o, c_o = c_oracle.pair_loss(d1[:1], c1[:1], d2[:1, 2:3], c2[:1, 2:3], rel[:1, 2:3], K, 1.0)
+    assert np.array_equal(got_c[0, 2], c_o[0, 0].astype(np.int64))
+    np.testing.assert_allclose(sums.cpu().numpy()[0, 2], s_o[0, 0], rtol=RTOL)
