@@ -151,6 +151,17 @@ int slamhip_warp_materialize(const uint16_t* depth1, const uint8_t* rgb1, const 
 int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16, float* out_f32,
                                int B, int H, int W, int C, int N, int flip, void* stream);
 
+/* The same forward convolution with the per-channel statistics of the next step
+ * (cnn_model.py:104, tf.nn.moments) taken in its epilogue: sums2c[n] = sum z,
+ * sums2c[N+n] = sum z^2 over all pixels of the bfloat16 output (float32 [2N],
+ * overwritten), saving slamhip_channel_stats' pass over z.  `workspace`: device
+ * memory of slamhip_conv_stats_workspace_bytes(B*H*W, N) bytes, contents
+ * irrelevant before and after.  No counterpart in the reference (a fusion). */
+size_t slamhip_conv_stats_workspace_bytes(long long pixels, int N);
+int slamhip_conv3x3_igemm_bf16_stats(const void* act, const void* w_nk, void* out_bf16, int B, int H,
+                                     int W, int C, int N, float* sums2c, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+
 /* cnn_model.py:74,123 (tf.matmul) - out[m][n] = sum_k a[m][k] * b[n][k]; a [M][K],
  * b [N][K] bf16, K % 64 == 0. */
 int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, float* out_f32, int M,
@@ -170,6 +181,11 @@ int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16
                               int W, int Cin, int Cout, void* stream);
 int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W,
                                 int Cin, int Cout, void* stream);
+/* ... and with the output's channel statistics, as slamhip_conv3x3_igemm_bf16_stats
+ * (Cout % 64 == 0). */
+int slamhip_conv3x3_small_fwd_stats(const void* x, const float* w_hwio, void* out_bf16, int B, int H,
+                                    int W, int Cin, int Cout, float* sums2c, void* workspace,
+                                    size_t workspace_bytes, void* stream);
 
 /* cnn_model.py:104-107 (tf.nn.moments over axes [0,1,2] +
  * tf.nn.batch_normalization with the batch statistics, in training and in

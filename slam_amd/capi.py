@@ -44,6 +44,11 @@ SIGNATURES = {
                                   _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p], _c_int),
     "slamhip_conv3x3_igemm_bf16": ([_c_void_p] * 4 + [_c_int] * 6 + [_c_void_p], _c_int),
+    "slamhip_conv_stats_workspace_bytes": ([ctypes.c_longlong, _c_int], ctypes.c_size_t),
+    "slamhip_conv3x3_igemm_bf16_stats": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, _c_void_p, ctypes.c_size_t,
+                                                                        _c_void_p], _c_int),
+    "slamhip_conv3x3_small_fwd_stats": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p, _c_void_p, ctypes.c_size_t,
+                                                                       _c_void_p], _c_int),
     "slamhip_gemm_nt_bf16": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
     "slamhip_wgrad_bf16": ([_c_void_p] * 3 + [_c_int] * 6 + [_c_void_p], _c_int),
     "slamhip_conv3x3_small_fwd": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p], _c_int),

@@ -28,6 +28,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_PITCH = 72;   // 64 bf16 of payload + 8 of padding per row (144 B)
 
+// Per-column sum and sum of squares of one wave's 32-column slice of an output tile, from the
+// values as they are stored (rounded to bfloat16): lanes l and l + 32 hold the same column,
+// lanes 0..31 write {sum, sum of squares} of column n to part[n] and part[N + n].
+__device__ __forceinline__ void store_column_stats(float s, float q, float* __restrict__ part, int n, int N, int lane) {
+  s += __shfl_xor(s, 32);
+  q += __shfl_xor(q, 32);
+  if (lane < 32 && n < N) { part[n] = s; part[N + n] = q; }
+}
+
 // Zeroing by mask keeps the value in registers (a select between two 16-byte values can
 // be lowered to an indexed read of a stack copy).
 __device__ __forceinline__ uint4 and4(uint4 v, uint32_t keep) {
@@ -44,7 +53,7 @@ template <int TAPS, int BN, bool WRITE_BF16, bool WRITE_F32>
 __global__ void __launch_bounds__(256)
 igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
                   float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip, int n_tiles,
-                  int total_tiles) {
+                  int total_tiles, float* __restrict__ stat_part) {
   constexpr int BM = 128;
   constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
   constexpr int NB = BN / 32;                 // B loader passes: 8 threads (16 B each) cover one 64-element row
@@ -162,6 +171,24 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
           if (WRITE_F32) out_f32[(long long)m * N + n] = v;
         }
       }
+  // optional: this wave's column statistics (rows beyond M hold zeros and add nothing),
+  // one record of 2N floats per (pixel tile, wave row)
+  if (stat_part) {
+    float* part = stat_part + ((long long)(work / n_tiles) * 2 + wm) * 2 * N;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (float)(bf16)acc[i][j][r];
+          sm += v;
+          sq = __builtin_fmaf(v, v, sq);
+        }
+      store_column_stats(sm, sq, part, n0 + wn * (BN / 2) + j * 32 + (lane & 31), N, lane);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -365,7 +392,7 @@ __device__ __forceinline__ uint2 and2(uint2 v, uint32_t keep) { return make_uint
 // forward: 128 pixels x 64 filters per workgroup, one K-step
 __global__ void __launch_bounds__(256)
 conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, bf16* __restrict__ out, int P,
-                          int H, int W) {
+                          int H, int W, float* __restrict__ stat_part) {
   __shared__ __attribute__((aligned(16))) bf16 As[128 * LDS_PITCH];
   __shared__ __attribute__((aligned(16))) bf16 Bs[64 * LDS_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -427,6 +454,18 @@ conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ 
       const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       if (m < P) out[(long long)m * 64 + wn * 32 + (lane & 31)] = (bf16)acc[i][r];
     }
+  if (stat_part) {
+    float sm = 0.f, sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = (float)(bf16)acc[i][r];
+        sm += v;
+        sq = __builtin_fmaf(v, v, sq);
+      }
+    store_column_stats(sm, sq, stat_part + ((long long)blockIdx.x * 2 + wm) * 128, wn * 32 + (lane & 31), 64, lane);
+  }
 }
 
 // filter gradient: dW[k][n] += sum_p A[p][k] dY[p][n] over a slice of the pixels
@@ -575,6 +614,20 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
     for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
     atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
   }
+}
+
+// second stage of the statistics that the convolution kernels leave per tile:
+// sums[c] += sum over the R records of part[r][c], c in [0, 2N)
+__global__ void __launch_bounds__(256)
+stat_finish_kernel(const float* __restrict__ part, float* __restrict__ sums, int R, int N2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= N2) return;
+  const int chunk = (R + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * chunk, r1 = min(R, r0 + chunk);
+  float a0 = 0.f, a1 = 0.f;
+  int r = r0;
+  for (; r + 1 < r1; r += 2) { a0 += part[(long long)r * N2 + c]; a1 += part[(long long)(r + 1) * N2 + c]; }
+  if (r < r1) a0 += part[(long long)r * N2 + c];
+  if (r0 < r1) atomicAdd(&sums[c], a0 + a1);
 }
 
 // Both element-wise batch-norm kernels walk the tensor with a stride that is a multiple of C
@@ -904,12 +957,12 @@ static unsigned int reduce_grid(long long P, int C) {
 
 template <int TAPS, int BN>
 static void launch_igemm(const void* a, const void* b, void* out_bf16, float* out_f32, long long M, int N, int C,
-                         int H, int W, int flip, hipStream_t s) {
+                         int H, int W, int flip, hipStream_t s, float* stat_part = nullptr) {
   const int m_tiles = (int)((M + 127) / 128), n_tiles = (N + BN - 1) / BN, total = m_tiles * n_tiles;
   const dim3 grid((total + 7) / 8 * 8), block(256);
 #define SLAMHIP_IGEMM_GO(WB, WF)                                                                                 \
   hipLaunchKernelGGL((igemm_bf16_kernel<TAPS, BN, WB, WF>), grid, block, 0, s, (const bf16*)a, (const bf16*)b, \
-                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total)
+                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total, stat_part)
   if (out_bf16 && out_f32) SLAMHIP_IGEMM_GO(true, true);
   else if (out_bf16) SLAMHIP_IGEMM_GO(true, false);
   else SLAMHIP_IGEMM_GO(false, true);
@@ -935,6 +988,39 @@ int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16
   else launch_igemm<9, 64>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
+}
+
+size_t slamhip_conv_stats_workspace_bytes(long long pixels, int N) {
+  if (pixels <= 0 || N <= 0) return 0;
+  return (size_t)((pixels + 127) / 128) * 2 * 2 * (size_t)N * sizeof(float);
+}
+
+// sums2c[0..2N) = column sums of the R per-tile records in ws
+static int finish_stats(const float* ws, float* sums2c, long long R, int N, hipStream_t s) {
+  SLAMHIP_HIP(hipMemsetAsync(sums2c, 0, sizeof(float) * 2 * (size_t)N, s));
+  long long slices = (R + 63) / 64;
+  if (slices > 512) slices = 512;
+  hipLaunchKernelGGL(stat_finish_kernel, dim3((2 * N + 255) / 256, (unsigned)slices), dim3(256), 0, s, ws, sums2c,
+                     (int)R, 2 * N);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv3x3_igemm_bf16_stats(const void* act, const void* w_nk, void* out_bf16, int B, int H, int W, int C,
+                                     int N, float* sums2c, void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && N > 0, SLAMHIP_E_ARG, "conv3x3_igemm_stats: bad shape");
+  SLAMHIP_REQUIRE(act && w_nk && out_bf16 && sums2c && workspace, SLAMHIP_E_ARG, "conv3x3_igemm_stats: null pointer");
+  SLAMHIP_REQUIRE(C % 64 == 0, SLAMHIP_E_SIZE, "conv3x3_igemm_stats: channels per tap (%d) must be a multiple of 64", C);
+  const long long M = (long long)B * H * W;
+  SLAMHIP_REQUIRE(M <= 0x7fffffffLL, SLAMHIP_E_SIZE, "conv3x3_igemm_stats: too many pixels");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_conv_stats_workspace_bytes(M, N), SLAMHIP_E_SIZE,
+                  "conv3x3_igemm_stats: workspace of %zu bytes, need %zu", workspace_bytes,
+                  slamhip_conv_stats_workspace_bytes(M, N));
+  hipStream_t s = (hipStream_t)stream;
+  if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
+  else launch_igemm<9, 64>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
+  SLAMHIP_HIP(hipGetLastError());
+  return finish_stats((const float*)workspace, sums2c, (M + 127) / 128 * 2, N, s);
 }
 
 int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, float* out_f32, int M, int N, int K,
@@ -994,22 +1080,48 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   return SLAMHIP_OK;
 }
 
+static int small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, int H, int W, int Cin, int Cout,
+                     float* stat_part, hipStream_t s) {
+  const long long total = (long long)B * H * W * Cout;
+  const int P = B * H * W;
+  if (Cin == 4 && Cout == 64) {
+    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3((P + 127) / 128), dim3(256), 0, s, (const bf16*)x, w_hwio,
+                       (bf16*)out_bf16, P, H, W, stat_part);
+  } else {
+    hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16*)x, w_hwio,
+                       (bf16*)out_bf16, P, H, W, Cin, Cout);
+  }
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
 int slamhip_conv3x3_small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, int H, int W, int Cin,
                               int Cout, void* stream) {
   SLAMHIP_REQUIRE(x && w_hwio && out_bf16 && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, SLAMHIP_E_ARG,
                   "conv3x3_small_fwd: bad argument");
-  const long long total = (long long)B * H * W * Cout;
-  if (total == 0) return SLAMHIP_OK;
-  const int P = B * H * W;
+  if (B == 0) return SLAMHIP_OK;
+  return small_fwd(x, w_hwio, out_bf16, B, H, W, Cin, Cout, nullptr, (hipStream_t)stream);
+}
+
+int slamhip_conv3x3_small_fwd_stats(const void* x, const float* w_hwio, void* out_bf16, int B, int H, int W, int Cin,
+                                    int Cout, float* sums2c, void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(x && w_hwio && out_bf16 && sums2c && B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 &&
+                      Cout % 64 == 0 && Cout <= 2048,
+                  SLAMHIP_E_ARG, "conv3x3_small_fwd_stats: bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const long long P = (long long)B * H * W;
   if (Cin == 4 && Cout == 64) {
-    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3((P + 127) / 128), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, w_hwio, (bf16*)out_bf16, P, H, W);
-  } else {
-    hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16*)x, w_hwio, (bf16*)out_bf16, P, H, W, Cin, Cout);
+    SLAMHIP_REQUIRE(workspace && workspace_bytes >= slamhip_conv_stats_workspace_bytes(P, Cout), SLAMHIP_E_SIZE,
+                    "conv3x3_small_fwd_stats: workspace of %zu bytes, need %zu", workspace_bytes,
+                    slamhip_conv_stats_workspace_bytes(P, Cout));
+    const int rc = small_fwd(x, w_hwio, out_bf16, B, H, W, Cin, Cout, (float*)workspace, s);
+    if (rc != SLAMHIP_OK) return rc;
+    return finish_stats((const float*)workspace, sums2c, (P + 127) / 128 * 2, Cout, s);
   }
-  SLAMHIP_HIP(hipGetLastError());
-  return SLAMHIP_OK;
+  // other channel counts: the direct kernel, then a pass over its output
+  const int rc = small_fwd(x, w_hwio, out_bf16, B, H, W, Cin, Cout, nullptr, s);
+  if (rc != SLAMHIP_OK) return rc;
+  return slamhip_channel_stats(out_bf16, sums2c, P, Cout, stream);
 }
 
 int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin, int Cout,

@@ -188,6 +188,8 @@ class VGG16Model:
                 h, w = h // 2, w // 2
                 a["pooled"] = torch.empty(B, h, w, co, **bf)
             self._act.append(a)
+        ws_bytes = max(ops.conv_stats_workspace_bytes(a["z"].numel() // a["cout"], a["cout"]) for a in self._act)
+        self._stats_ws = torch.empty(max(ws_bytes, 16) // 4, **f32)
         self._fc = {}
         for name, k_in, n_out in (("fc6-conv", feat, self.fc_dim), ("fc7-conv", self.fc_dim, self.fc_dim),
                                   ("out_layer", self.fc_dim, OUT_PAD)):
@@ -265,15 +267,18 @@ class VGG16Model:
         h = self._x
         for i, a in enumerate(self._act):
             n = a["name"]
-            if i == 0:
+            if self.batch_norm:     # the channel statistics come out of the convolution's epilogue
+                if i == 0:
+                    ops.conv3x3_small_stats(h, self.params[n + "/weights"], a["z"], a["sums"], self._stats_ws)
+                else:
+                    ops.conv3x3_stats(h, self._w_fwd[n], a["z"], a["sums"], self._stats_ws)
+                bn = self.params[n + "/bn"]
+                ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
+            elif i == 0:
                 ops.conv3x3_small(h, self.params[n + "/weights"], a["z"])
             else:
                 ops.conv3x3(h, self._w_fwd[n], out_bf16=a["z"])
-            if self.batch_norm:
-                bn = self.params[n + "/bn"]
-                ops.channel_stats(a["z"], a["sums"])
-                ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
-            else:
+            if not self.batch_norm:
                 ops.bias_relu(a["z"], self.params[n + "/biases"], a["y"])
             h = a["y"]
             if a["pool"]:

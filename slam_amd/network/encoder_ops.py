@@ -223,3 +223,26 @@ def bias_relu_bwd(dy, y, dz, dbias):
     assert _chk(dy, BF16, "dy").shape == y.shape and _chk(dz, BF16, "dz").shape == y.shape
     assert _chk(dbias, F32, "dbias").shape == (C,) and C % 64 == 0
     _call("slamhip_bias_relu_bwd", capi.ptr(dy), capi.ptr(y), capi.ptr(dz), capi.ptr(dbias), y.numel() // C, C)
+
+
+def conv_stats_workspace_bytes(pixels, N):
+    return int(capi.load().slamhip_conv_stats_workspace_bytes(int(pixels), int(N)))
+
+
+def conv3x3_stats(act, w_nk, out_bf16, sums2c, workspace):
+    """Forward convolution + per-channel sums of its output (see channel_stats) in one pass."""
+    B, H, W, C = _chk(act, BF16, "act").shape
+    N = _chk(w_nk, BF16, "w_nk").shape[0]
+    assert w_nk.shape == (N, 9 * C) and C % 64 == 0 and _chk(out_bf16, BF16, "out").shape == (B, H, W, N)
+    assert _chk(sums2c, F32, "sums").shape == (2, N) and workspace.is_cuda and workspace.is_contiguous()
+    _call("slamhip_conv3x3_igemm_bf16_stats", capi.ptr(act), capi.ptr(w_nk), capi.ptr(out_bf16), B, H, W, C, N,
+          capi.ptr(sums2c), capi.ptr(workspace), workspace.numel() * workspace.element_size())
+
+
+def conv3x3_small_stats(x, w_hwio, out, sums2c, workspace):
+    B, H, W, cin = _chk(x, BF16, "x").shape
+    cout = _chk(w_hwio, F32, "w").shape[3]
+    assert w_hwio.shape == (3, 3, cin, cout) and _chk(out, BF16, "out").shape == (B, H, W, cout)
+    assert _chk(sums2c, F32, "sums").shape == (2, cout) and workspace.is_cuda and workspace.is_contiguous()
+    _call("slamhip_conv3x3_small_fwd_stats", capi.ptr(x), capi.ptr(w_hwio), capi.ptr(out), B, H, W, cin, cout,
+          capi.ptr(sums2c), capi.ptr(workspace), workspace.numel() * workspace.element_size())

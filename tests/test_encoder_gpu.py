@@ -256,3 +256,28 @@ def test_bias_relu_layer(ops, shape, C):
     ops.bias_relu_bwd(dy.cuda().to(BF), yd, dz, db)
     close(dz, z.grad)
     close(db, b.grad, rtol=5e-3)
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 9, 11, 64, 64), (1, 14, 14, 128, 256), (3, 10, 12, 4, 64)])
+def test_conv_with_fused_statistics(ops, B, H, W, C, N):
+    """The statistics from the convolution's epilogue equal those of a separate pass over
+    the stored bfloat16 output."""
+    x = rnd(B, H, W, C, seed=40).cuda().to(BF)
+    w = rnd(3, 3, C, N, seed=41, scale=0.05).cuda()
+    out = torch.empty(B, H, W, N, dtype=BF, device="cuda")
+    sums = torch.full((2, N), 9.0, device="cuda")
+    ws = torch.empty(max(ops.conv_stats_workspace_bytes(B * H * W, N), 16) // 4, device="cuda")
+    if C == 4:
+        ops.conv3x3_small_stats(x, w, out, sums, ws)
+        ref_out = torch.empty_like(out)
+        ops.conv3x3_small(x, w, ref_out)
+    else:
+        w_fwd = torch.empty(N, 9 * C, dtype=BF, device="cuda")
+        ops.conv_weight_layouts(w, w_fwd, None)
+        ops.conv3x3_stats(x, w_fwd, out, sums, ws)
+        ref_out = torch.empty_like(out)
+        ops.conv3x3(x, w_fwd, out_bf16=ref_out)
+    assert torch.equal(out, ref_out)
+    z = out.float().reshape(-1, N).double()
+    close(sums[0], z.sum(0).float().cpu(), rtol=1e-5, atol=1e-3)
+    close(sums[1], (z * z).sum(0).float().cpu(), rtol=1e-5, atol=1e-3)
