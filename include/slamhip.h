@@ -256,6 +256,20 @@ int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long 
                       float beta1, float beta2, float eps, int step, float grad_scale,
                       void* stream);
 
+/* ---- device: input preparation of the RGB-D trainers --------------------------
+ * slam/network/model_input.py:427-450 + :360-362,517-522 for a batch of raw frames
+ * resident in HBM: rgb uint8 [B,Hs,Ws,3], depth uint16 [B,Hs,Ws] ->
+ * depth' = 255 * depth / max(depth) (integer division; max per frame),
+ * 4-channel concat, bilinear resize to Ho x Wo (sample centres (i + 0.5) * Hs / Ho
+ * - 0.5, clamped), float32, minus the per-channel mean of the whole batch.
+ * out_f32 [B,Ho,Wo,4]; out_bf16 (may be NULL) the same rounded to bfloat16 (the
+ * encoder's input format); mean4 (may be NULL) float64 [4] the subtracted mean.
+ * workspace: slamhip_prep_rgbd_workspace_bytes(B) bytes, contents irrelevant. */
+size_t slamhip_prep_rgbd_workspace_bytes(int B);
+int slamhip_prep_rgbd(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, int Ws, int Ho, int Wo,
+                      float* out_f32, void* out_bf16, double* mean4, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
 /* cnn_model.py:167-170 - the other two optimizers the configuration may name:
  * tf.train.GradientDescentOptimizer (p -= lr g) and tf.train.RMSPropOptimizer
  * with momentum 0 (ms = decay ms + (1-decay) g^2; p -= lr g / sqrt(ms + eps);

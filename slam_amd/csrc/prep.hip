@@ -1,0 +1,137 @@
+// Input preparation of the RGB-D trainers on the GPU (slam/network/model_input.py:427-450
+// and the per-batch mean subtraction of :360-362, :517-522): per frame
+//   depth -> 255 * depth / max(depth)   (integer division, as the Python-2 reference)
+//   concat with RGB to 4 channels, bilinear resize to Ho x Wo, float32
+// then the per-batch channel mean is subtracted.  The resize restates
+// skimage.transform.resize(order=1) as interpolation at half-pixel centres with edge
+// clamping (the library is not available to pin it; the host implementation in
+// slam_amd/network/model_input.py uses the same definition).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "common.h"
+
+namespace slamhip {
+
+typedef __bf16 bf16_t;
+
+// max of each frame's raw depth (uint32 per frame, zeroed by the caller)
+__global__ void __launch_bounds__(256)
+depth_max_kernel(const uint16_t* __restrict__ depth, unsigned int* __restrict__ dmax, long long hw) {
+  const int b = blockIdx.y;
+  const uint16_t* d = depth + (long long)b * hw;
+  unsigned int m = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < hw; i += (long long)gridDim.x * blockDim.x)
+    m = max(m, (unsigned int)d[i]);
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned int)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(&dmax[b], m);
+}
+
+// one thread per output pixel: 4 channels, float64 interpolation, float32 result;
+// per-channel sums of the batch (float64 atomics) for the mean
+__global__ void __launch_bounds__(256)
+resize_rgbd_kernel(const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth,
+                   const unsigned int* __restrict__ dmax, float* __restrict__ out, double* __restrict__ sums, int B,
+                   int Hs, int Ws, int Ho, int Wo) {
+  __shared__ double part[4][4];
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)B * Ho * Wo;
+  double v[4] = {0.0, 0.0, 0.0, 0.0};
+  if (idx < total) {
+    const int xo = (int)(idx % Wo);
+    const int yo = (int)((idx / Wo) % Ho);
+    const int b = (int)(idx / ((long long)Wo * Ho));
+    double ys = ((double)yo + 0.5) * (double)Hs / (double)Ho - 0.5;
+    double xs = ((double)xo + 0.5) * (double)Ws / (double)Wo - 0.5;
+    ys = fmin(fmax(ys, 0.0), (double)(Hs - 1));
+    xs = fmin(fmax(xs, 0.0), (double)(Ws - 1));
+    const int y0 = (int)floor(ys), x0 = (int)floor(xs);
+    const int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+    const double fy = ys - (double)y0, fx = xs - (double)x0;
+    const long long base = (long long)b * Hs * Ws;
+    const long long o00 = base + (long long)y0 * Ws + x0, o01 = base + (long long)y0 * Ws + x1;
+    const long long o10 = base + (long long)y1 * Ws + x0, o11 = base + (long long)y1 * Ws + x1;
+    const unsigned int mx = max(dmax[b], 1u);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      double a, bq, cq, e;
+      if (c < 3) {
+        a = rgb[3 * o00 + c]; bq = rgb[3 * o01 + c]; cq = rgb[3 * o10 + c]; e = rgb[3 * o11 + c];
+      } else {
+        a = (double)(255u * depth[o00] / mx); bq = (double)(255u * depth[o01] / mx);
+        cq = (double)(255u * depth[o10] / mx); e = (double)(255u * depth[o11] / mx);
+      }
+      const double top = a * (1.0 - fx) + bq * fx, bot = cq * (1.0 - fx) + e * fx;
+      v[c] = top * (1.0 - fy) + bot * fy;
+      out[idx * 4 + c] = (float)v[c];
+      v[c] = (double)(float)v[c];     // the mean is taken over the float32 images
+    }
+  }
+  // block sums -> one atomic per channel
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    double s = v[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][c] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(&sums[threadIdx.x], (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+// out -= mean (float32 arithmetic on a float64 mean, like numpy's float32 - float64 -> float64 -> cast)
+__global__ void __launch_bounds__(256)
+subtract_mean_kernel(float* __restrict__ out, bf16_t* __restrict__ out_bf16, const double* __restrict__ sums,
+                     double* __restrict__ mean_out, long long total4, double inv_count) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && mean_out) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) mean_out[c] = sums[c] * inv_count;
+  }
+  if (i >= total4) return;
+  float4 v = reinterpret_cast<float4*>(out)[i];
+  v.x = (float)((double)v.x - sums[0] * inv_count);
+  v.y = (float)((double)v.y - sums[1] * inv_count);
+  v.z = (float)((double)v.z - sums[2] * inv_count);
+  v.w = (float)((double)v.w - sums[3] * inv_count);
+  reinterpret_cast<float4*>(out)[i] = v;
+  if (out_bf16) {
+    out_bf16[4 * i] = (bf16_t)v.x; out_bf16[4 * i + 1] = (bf16_t)v.y;
+    out_bf16[4 * i + 2] = (bf16_t)v.z; out_bf16[4 * i + 3] = (bf16_t)v.w;
+  }
+}
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+extern "C" {
+
+size_t slamhip_prep_rgbd_workspace_bytes(int B) { return B > 0 ? 64 + sizeof(unsigned int) * (size_t)B : 0; }
+
+int slamhip_prep_rgbd(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, int Ws, int Ho, int Wo, float* out_f32,
+                      void* out_bf16, double* mean4, void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, SLAMHIP_E_ARG, "prep_rgbd: bad shape");
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(rgb && depth && out_f32 && workspace, SLAMHIP_E_ARG, "prep_rgbd: null pointer");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_prep_rgbd_workspace_bytes(B), SLAMHIP_E_SIZE,
+                  "prep_rgbd: workspace of %zu bytes, need %zu", workspace_bytes, slamhip_prep_rgbd_workspace_bytes(B));
+  SLAMHIP_REQUIRE((long long)Hs * Ws <= 0x7fffffffLL && (long long)B * Ho * Wo <= 0x7fffffffLL, SLAMHIP_E_SIZE,
+                  "prep_rgbd: too many pixels");
+  hipStream_t s = (hipStream_t)stream;
+  double* sums = (double*)workspace;                              // 4 doubles (+ padding to 64 bytes)
+  unsigned int* dmax = (unsigned int*)((char*)workspace + 64);    // B
+  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, slamhip_prep_rgbd_workspace_bytes(B), s));
+  const long long hw = (long long)Hs * Ws;
+  hipLaunchKernelGGL(depth_max_kernel, dim3((unsigned)((hw + 4095) / 4096 < 64 ? (hw + 4095) / 4096 : 64), B), dim3(256), 0,
+                     s, depth, dmax, hw);
+  const long long total = (long long)B * Ho * Wo;
+  hipLaunchKernelGGL(resize_rgbd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rgb, depth, dmax, out_f32,
+                     sums, B, Hs, Ws, Ho, Wo);
+  hipLaunchKernelGGL(subtract_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_f32,
+                     (bf16_t*)out_bf16, sums, mean4, total, 1.0 / (double)total);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

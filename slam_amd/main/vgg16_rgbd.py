@@ -20,6 +20,7 @@ import torch
 
 from slam_amd.network.cnn_model import VGG16Model
 from slam_amd.network.model_config import get_config_provider
+from slam_amd.network import prep
 from slam_amd.network.model_input import get_simple_input_provider, write_synthetic_sequence
 
 
@@ -30,6 +31,8 @@ def main(argv=None):
     ap.add_argument("--synthetic", default=None, metavar="DIR",
                     help="write synthetic TUM-shaped sequences for the configured names into DIR and train on them")
     ap.add_argument("--synthetic-frames", type=int, default=8)
+    ap.add_argument("--gpu-prep", action="store_true",
+                    help="upload raw frames and do depth scaling, resize and mean subtraction on the GPU")
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many training steps (0 = no limit)")
     ap.add_argument("--epochs", type=int, default=0, help="override the configured number of epochs")
     a = ap.parse_args(argv)
@@ -73,11 +76,17 @@ def main(argv=None):
     apply_gradient_op = vgg_model.add_optimizer()
 
     input_provider = get_simple_input_provider(config_provider.training_filenames, base_data_dir=data_dir)
+    input_provider.raw_frames = a.gpu_prep
     steps, loss_value = 0, float("nan")
     for step in range(epoch):
         logger.info('Executing step:%d', step)
         for i, sequence_batch in enumerate(input_provider.complete_seq_iter()):
-            rgbd_input_batch.copy_(torch.from_numpy(np.stack(sequence_batch.rgbd_images)))
+            if a.gpu_prep:
+                rgb = torch.from_numpy(np.stack([f[0] for f in sequence_batch.rgbd_images])).to(dev)
+                depth = torch.from_numpy(np.stack([f[1] for f in sequence_batch.rgbd_images])).to(dev)
+                prep.rgbd_batch(rgb, depth, (img_h, img_w), out=rgbd_input_batch)
+            else:
+                rgbd_input_batch.copy_(torch.from_numpy(np.stack(sequence_batch.rgbd_images)))
             groundtruth_batch.copy_(torch.from_numpy(np.stack(sequence_batch.groundtruths).astype(np.float32)))
             # the first frame of a sequence has no motion label: zero weight (vgg16_rgbd.py:51)
             loss_weight.copy_(torch.zeros(6, 6) if i == 0 else torch.eye(6))

@@ -96,15 +96,20 @@ class SimpleInputProvider:
             if self.counter >= self.sequence_length:
                 raise StopIteration()
             batch = SimpleInputProvider.SequenceBatch()
+            raw = self.input_provider.raw_frames
             for i, (seqdir, offset) in enumerate(self.seqdir_vs_offset):
-                rgb_filename, depth_filename, rgbd = self.input_provider.get_rgbd_file(seqdir, offset)
+                if raw:     # (uint8 rgb, uint16 depth): scaling, resize and mean are left to the GPU
+                    rgb_filename, depth_filename, rgbd = self.input_provider.get_raw_rgbd_file(seqdir, offset)
+                else:
+                    rgb_filename, depth_filename, rgbd = self.input_provider.get_rgbd_file(seqdir, offset)
                 batch.rgbd_images.append(rgbd)
                 batch.groundtruths.append(self.input_provider.get_ground_truth(seqdir, offset))
                 batch.rgb_filenames.append(rgb_filename)
                 batch.depth_filenames.append(depth_filename)
                 self.seqdir_vs_offset[i][1] = offset + 1
-            mean = get_mean(batch.rgbd_images, channels=4)
-            batch.rgbd_images = [image - mean for image in batch.rgbd_images]
+            if not raw:
+                mean = get_mean(batch.rgbd_images, channels=4)
+                batch.rgbd_images = [image - mean for image in batch.rgbd_images]
             self.counter += 1
             return batch
 
@@ -116,6 +121,7 @@ class SimpleInputProvider:
         base = self.BASE_DATA_DIR if base_data_dir is None else base_data_dir
         self.sequence_dirs = [os.path.join(base, name) for name in filename_provider()]
         self.image_reader = image_reader
+        self.raw_frames = False     # True: batches carry raw frames for slam_amd.network.prep.rgbd_batch
         self.seq_dir_map = {}
         for seq_dir in self.sequence_dirs:
             associations = np.loadtxt(os.path.join(seq_dir, "associate.txt"), dtype="str", unpack=False)
@@ -158,6 +164,19 @@ class SimpleInputProvider:
         rgbd_img = np.concatenate((rgb_img, depth_img), 2)
         rgbd_img = resize_bilinear(rgbd_img, 224, 224)
         return rgb_filename, depth_filename, rgbd_img.astype(np.float32)
+
+    def _frame_paths(self, dirname, offset):
+        associations = self.seq_dir_map[dirname]['associations']
+        if associations[offset, 1].startswith('depth'):
+            return os.path.join(dirname, associations[offset, 3]), os.path.join(dirname, associations[offset, 1])
+        return os.path.join(dirname, associations[offset, 1]), os.path.join(dirname, associations[offset, 3])
+
+    def get_raw_rgbd_file(self, dirname, offset):
+        """(rgb path, depth path, (uint8 [H,W,3], uint16 [H,W])): the frame as stored."""
+        rgb_filename, depth_filename = self._frame_paths(dirname, offset)
+        rgb_img = np.ascontiguousarray(self.image_reader(rgb_filename), np.uint8)
+        depth_img = np.ascontiguousarray(self.image_reader(depth_filename)).astype(np.uint16)
+        return rgb_filename, depth_filename, (rgb_img, depth_img)
 
     def get_ground_truth(self, dirname, offset):
         return self.seq_dir_map[dirname]['relpos'][offset, :]

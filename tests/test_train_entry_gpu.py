@@ -24,6 +24,10 @@ def test_vgg16_rgbd_entry_point_runs(tmp_path, monkeypatch):
     from slam_amd.main import vgg16_rgbd
     loss = vgg16_rgbd.main(["--synthetic", str(tmp_path / "tum"), "--synthetic-frames", "4", "--epochs", "1"])
     assert np.isfinite(loss)
+    # the same run with the input preparation on the GPU sees the same data
+    monkeypatch.setattr(mc, "_config_provider", None)
+    loss_gpu_prep = vgg16_rgbd.main(["--synthetic", str(tmp_path / "tum"), "--epochs", "1", "--gpu-prep"])
+    assert np.isfinite(loss_gpu_prep)
     saved = torch.load(str(tmp_path / "log" / "checkpoints" / "learned_weights.pt"), weights_only=True)
     assert saved["conv1_1/weights"].shape == (3, 3, 4, 64) and saved["fc6-conv/weights"].shape == (25088, 4096)
     monkeypatch.setattr(mc, "_config_provider", None)
