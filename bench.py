@@ -57,12 +57,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s):
-    """C restatement of the oracle, one host core, bounded sample."""
+def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s, threads=1):
+    """C restatement of the oracle on `threads` host threads, bounded sample."""
     from oracle import c_oracle
-    n = min(8, d1.shape[0])
-    args = (d1[:n], c1[:n], d2[:n], c2[:n], rel[:n], K, factor)
-    c_oracle.pair_loss(*args)  # touch pages / load the library
+    n = min(8 if threads == 1 else 4 * threads, d1.shape[0])
+    args = (d1[:n], c1[:n], d2[:n], c2[:n], rel[:n], K, factor, threads)
+    c_oracle.pair_loss(*args)  # touch pages / load the library / start the threads
     done, t0 = 0, time.perf_counter()
     while True:
         sums, counts = c_oracle.pair_loss(*args)
@@ -70,9 +70,10 @@ def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s):
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    return dict(value=done / el, unit="frame pairs/s", cores=1, kind="port",
+    return dict(value=done / el, unit="frame pairs/s", cores=threads, kind="port",
                 sample="%d pairs (the first %d anchors of rank 0's batch, repeated) in %.1f s, "
-                       "oracle/slam_oracle.c single-threaded" % (done, n, el)), sums, counts
+                       "oracle/slam_oracle.c, %s" % (done, n, el, "single-threaded" if threads == 1 else
+                                                     "OpenMP over pairs, %d threads" % threads)), sums, counts
 
 
 def main():
@@ -163,6 +164,9 @@ def main():
                        "step_ms": enc["step_ms"], "steps": a.encoder_steps,
                        "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                     "frac": tfl / peak, "flops": "model FLOPs of the whole step / step time, per GPU"}}
+            if world == 1 and rank == 0 and a.cpu_seconds > 0:
+                from oracle import torch_encoder
+                encoder["cpu_baseline"] = torch_encoder.timed_training_steps(8, budget_s=a.cpu_seconds)
         except Exception as e:   # the headline line must survive a failure here
             encoder = {"error": "%s: %s" % (type(e).__name__, e)}
 
@@ -171,9 +175,19 @@ def main():
         last = bufs[(a.steps - 1) % len(bufs)] if a.steps else bufs[0]
         cb = None
         verified = None
+        cb_all = None
         if a.cpu_seconds > 0:
             host = [t.cpu().numpy() for t in last]
-            cb, o_s, o_c = cpu_baseline(host[0], host[1], host[2], host[3], host[4], K, a.factor, a.cpu_seconds)
+            # timed on one GPU only (the host cores are shared by the ranks otherwise); with
+            # several ranks the oracle still checks the last step's results, untimed
+            budget = a.cpu_seconds if world == 1 else 0.0
+            cb, o_s, o_c = cpu_baseline(host[0], host[1], host[2], host[3], host[4], K, a.factor, budget)
+            if world == 1:
+                threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "8")), os.cpu_count() or 1, 16))
+                cb_all = cpu_baseline(host[0], host[1], host[2], host[3], host[4], K, a.factor,
+                                      a.cpu_seconds / 2, threads=threads)[0]
+            else:
+                cb = None
             n = o_s.shape[0]
             sums, counts = plans[(a.steps - 1) % len(plans)].sums, plans[(a.steps - 1) % len(plans)].counts
             got_c = counts[:n].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
@@ -213,6 +227,7 @@ def main():
                          "kernel": "pair_loss_fused_kernel", "launch_ms": launch_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "cpu_baseline": cb,
+            "cpu_baseline_all_cores": cb_all,
             "verified_against_oracle": verified,
             "encoder": encoder,
         }

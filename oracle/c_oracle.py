@@ -18,6 +18,7 @@ def load():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.slam_oracle_pair.restype = None
         _lib.slam_oracle_pair_loss.restype = None
+        _lib.slam_oracle_pair_loss_mt.restype = None
     return _lib
 
 
@@ -25,8 +26,9 @@ def _p(a):
     return None if a is None else ctypes.c_void_p(a.ctypes.data)
 
 
-def pair_loss(d1, c1, d2, c2, rel, K, factor):
-    """Same contract as slam_oracle.pair_loss (numpy in, numpy out)."""
+def pair_loss(d1, c1, d2, c2, rel, K, factor, threads=1):
+    """Same contract as slam_oracle.pair_loss (numpy in, numpy out); `threads` host threads
+    share the pairs (the results do not depend on it)."""
     d1 = np.ascontiguousarray(d1, np.uint16)
     c1 = np.ascontiguousarray(c1, np.uint8)
     B, H, W = d1.shape
@@ -37,8 +39,8 @@ def pair_loss(d1, c1, d2, c2, rel, K, factor):
     Kc = (ctypes.c_double * 4)(*[float(x) for x in K])
     sums = np.zeros((B, k, 4))
     counts = np.zeros((B, k, 4), np.uint32)
-    load().slam_oracle_pair_loss(_p(d1), _p(c1), _p(d2), _p(c2), _p(rel), Kc, ctypes.c_double(float(factor)),
-                                 B, k, H, W, _p(sums), _p(counts))
+    load().slam_oracle_pair_loss_mt(_p(d1), _p(c1), _p(d2), _p(c2), _p(rel), Kc, ctypes.c_double(float(factor)),
+                                    B, k, H, W, _p(sums), _p(counts), int(threads))
     return sums, counts
 
 

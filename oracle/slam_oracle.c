@@ -115,16 +115,29 @@ void slam_oracle_pair(const uint16_t* d1, const uint8_t* c1, const uint16_t* d2,
   if (counts) { counts[0] = n0; counts[1] = n1; counts[2] = n2; counts[3] = n3; }
 }
 
+void slam_oracle_pair_loss_mt(const uint16_t* d1, const uint8_t* c1, const uint16_t* d2, const uint8_t* c2,
+                              const double* rel, const double* K, double factor, int B, int k, int H, int W,
+                              double* sums, uint32_t* counts, int threads);
+
 /* Batched front end of the reduction: depth1 [B,H,W], rgb1 [B,H,W,3], depth2
  * [B,k,H,W], rgb2 [B,k,H,W,3], rel [B,k,16] -> sums [B,k,4], counts [B,k,4]. */
 void slam_oracle_pair_loss(const uint16_t* d1, const uint8_t* c1, const uint16_t* d2, const uint8_t* c2,
                            const double* rel, const double* K, double factor, int B, int k, int H, int W,
                            double* sums, uint32_t* counts) {
+  slam_oracle_pair_loss_mt(d1, c1, d2, c2, rel, K, factor, B, k, H, W, sums, counts, 1);
+}
+
+/* The same over `threads` host threads (OpenMP over the independent pairs): the
+ * all-cores CPU baseline of the benchmark.  Results do not depend on `threads`. */
+void slam_oracle_pair_loss_mt(const uint16_t* d1, const uint8_t* c1, const uint16_t* d2, const uint8_t* c2,
+                              const double* rel, const double* K, double factor, int B, int k, int H, int W,
+                              double* sums, uint32_t* counts, int threads) {
   const long HW = (long)H * W;
-  for (int b = 0; b < B; ++b)
-    for (int j = 0; j < k; ++j) {
-      const long bj = (long)b * k + j;
-      slam_oracle_pair(d1 + b * HW, c1 + 3 * b * HW, d2 + bj * HW, c2 + 3 * bj * HW, rel + 16 * bj, K,
-                       factor, H, W, sums + 4 * bj, counts + 4 * bj, 0, 0, 0, 0, 0, 0, 0, 0, 0);
-    }
+  const long n = (long)B * k;
+#pragma omp parallel for schedule(dynamic, 1) num_threads(threads > 0 ? threads : 1)
+  for (long bj = 0; bj < n; ++bj) {
+    const long b = bj / k;
+    slam_oracle_pair(d1 + b * HW, c1 + 3 * b * HW, d2 + bj * HW, c2 + 3 * bj * HW, rel + 16 * bj, K,
+                     factor, H, W, sums + 4 * bj, counts + 4 * bj, 0, 0, 0, 0, 0, 0, 0, 0, 0);
+  }
 }

@@ -12,32 +12,10 @@ pytestmark = pytest.mark.gpu
 
 
 def torch_reference(model, x, gt, Wl, eps, storage_rounding):
-    """float32 autograd restatement; parameters are cloned from the model.
-    storage_rounding=True rounds weights and stored activations to bfloat16 at the points
-    where the GPU path stores them (straight-through for the gradient), which isolates
-    kernel errors from the precision of the storage format."""
-    from slam_amd.network.cnn_model import CONV_LAYERS
+    """float32 autograd restatement (oracle/torch_encoder.py); parameters are cloned from the model."""
+    from oracle import torch_encoder
     P = {k: v.detach().cpu().clone().requires_grad_() for k, v in model.params.items()}
-
-    def q(t):
-        return t + (t.to(torch.bfloat16).float() - t).detach() if storage_rounding else t
-
-    h = x.permute(0, 3, 1, 2)
-    for i, (name, _, pool) in enumerate(CONV_LAYERS):
-        w = P[name + "/weights"]
-        h = q(F.conv2d(h, q(w).permute(3, 2, 0, 1), padding=1))
-        mean = h.mean(dim=(0, 2, 3), keepdim=True)
-        var = h.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
-        bn = P[name + "/bn"]
-        h = q(torch.relu((h - mean) * torch.rsqrt(var + eps) * bn[1].view(1, -1, 1, 1) + bn[0].view(1, -1, 1, 1)))
-        if pool:
-            h = F.max_pool2d(h, 2)
-    h = h.permute(0, 2, 3, 1).reshape(x.shape[0], -1)     # NHWC flatten, as tf.reshape does
-    h = q(torch.relu(h @ q(P["fc6-conv/weights"]) + P["fc6-conv/bias"]))
-    h = q(torch.relu(h @ q(P["fc7-conv/weights"]) + P["fc7-conv/bias"]))
-    D = gt.shape[1]
-    out = h @ q(P["out_layer/weights"])[:, :D] + P["out_layer/bias"][:D]
-    loss = 0.5 * (((out - gt) @ Wl) ** 2).sum()
+    out, loss = torch_encoder.forward_loss(P, x, gt, Wl, eps, storage_rounding)
     loss.backward()
     return out.detach(), loss.detach(), P
 
