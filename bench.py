@@ -150,7 +150,7 @@ def main():
     if a.encoder_steps > 0:
         try:
             from slam_amd.network.cnn_model import timed_training_steps
-            enc = timed_training_steps(128 if world == 1 else 64, a.encoder_steps, warmup=2, seed=rank)
+            enc = timed_training_steps(128 if world == 1 else 64, a.encoder_steps, warmup=2, seed=0, data_seed=rank)
             if dist is not None:
                 t = torch.tensor([enc["step_ms"]], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -54,12 +54,12 @@ def model_flops(batch, height, width, in_channels=4, fc_dim=4096, output_dim=6):
     return fwd, 3 * fwd - first
 
 
-def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0):
+def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, data_seed=0):
     """Random-initialised encoder on synthetic input: `steps` training steps (forward, loss,
     backward, gradient all-reduce when torch.distributed is initialised, Adam) timed with
     one event pair on the launching stream.  Returns a dict for benchmark reports."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    g = torch.Generator(device=dev).manual_seed(seed)
+    g = torch.Generator(device=dev).manual_seed(data_seed)     # data differ per rank, parameters do not
     x = torch.randn(batch, height, width, 4, device=dev, generator=g)
     model = VGG16Model(batch, x, 6, 1e-3, seed=seed)
     model.build_graph()
