@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -1047,8 +1048,12 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "wgrad: too many pixels");
   const int TM = Cin % 128 == 0 ? 128 : 64, TN = Cout % 128 == 0 ? 128 : 64;
   const long long tiles = (long long)(Cin / TM) * (Cout / TN) * taps;
-  long long splitk = (1024 + tiles - 1) / tiles;                      // aim at >= 1024 workgroups
-  const long long max_split = (P + 511) / 512;                          // at least 512 pixels per slice
+  static const long long target_blocks = [] {
+    const char* e = getenv("SLAMHIP_WGRAD_BLOCKS");     // tuning knob
+    return e ? atoll(e) : 2048LL;
+  }();
+  long long splitk = (target_blocks + tiles - 1) / tiles;             // aim at >= target_blocks workgroups
+  const long long max_split = (P + 2047) / 2048;                        // at least 2048 pixels per slice
   if (splitk > max_split) splitk = max_split;
   if (splitk < 1) splitk = 1;
   // slices are rounded up to 64 pixels; drop the ones that rounding leaves empty
