@@ -54,7 +54,7 @@ template <int TAPS, int BN, bool WRITE_BF16, bool WRITE_F32>
 __global__ void __launch_bounds__(256)
 igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
                   float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip, int n_tiles,
-                  int total_tiles, float* __restrict__ stat_part) {
+                  int total_tiles, float* __restrict__ stat_part, int splitk) {
   constexpr int BM = 128;
   constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
   constexpr int NB = BN / 32;                 // B loader passes: 8 threads (16 B each) cover one 64-element row
@@ -63,6 +63,8 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 
   // Workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of
   // tiles so the n-tiles of a pixel tile and its neighbours (tap halos) share an L2.
+  // splitk > 1 (plain GEMM with few tiles): blockIdx.y owns a slice of the K-steps and adds
+  // its partial tile to the zeroed float32 output
   const int per_xcd = (total_tiles + 7) >> 3;
   const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (work >= total_tiles) return;
@@ -104,10 +106,14 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int ksteps = TAPS * (C / 64);
+  const int ksteps_all = TAPS * (C / 64);
+  const int kchunk = (ksteps_all + splitk - 1) / splitk;
+  const int ks_begin = (TAPS == 1) ? (int)blockIdx.y * kchunk : 0;
+  const int ksteps = (TAPS == 1) ? min(ksteps_all, ks_begin + kchunk) - ks_begin : ksteps_all;
+  if (ksteps <= 0) return;
   uint4 ra0, ra1, ra2, ra3, rb[NB];
   bool a_ok;
-  int tap = 0, c0 = 0;   // position of the loads in flight
+  int tap = 0, c0 = ks_begin * 64;   // position of the loads in flight
 
 #define SLAMHIP_IGEMM_ISSUE()                                                                   \
   {                                                                                             \
@@ -169,7 +175,10 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
         if (m < M && n < N) {
           const float v = acc[i][j][r];
           if (WRITE_BF16) out_bf16[(long long)m * N + n] = (bf16)v;
-          if (WRITE_F32) out_f32[(long long)m * N + n] = v;
+          if (WRITE_F32) {
+            if (TAPS == 1 && splitk > 1) atomicAdd(&out_f32[(long long)m * N + n], v);
+            else out_f32[(long long)m * N + n] = v;
+          }
         }
       }
   // optional: this wave's column statistics (rows beyond M hold zeros and add nothing),
@@ -958,12 +967,12 @@ static unsigned int reduce_grid(long long P, int C) {
 
 template <int TAPS, int BN>
 static void launch_igemm(const void* a, const void* b, void* out_bf16, float* out_f32, long long M, int N, int C,
-                         int H, int W, int flip, hipStream_t s, float* stat_part = nullptr) {
+                         int H, int W, int flip, hipStream_t s, float* stat_part = nullptr, int splitk = 1) {
   const int m_tiles = (int)((M + 127) / 128), n_tiles = (N + BN - 1) / BN, total = m_tiles * n_tiles;
-  const dim3 grid((total + 7) / 8 * 8), block(256);
+  const dim3 grid((total + 7) / 8 * 8, splitk), block(256);
 #define SLAMHIP_IGEMM_GO(WB, WF)                                                                                 \
   hipLaunchKernelGGL((igemm_bf16_kernel<TAPS, BN, WB, WF>), grid, block, 0, s, (const bf16*)a, (const bf16*)b, \
-                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total, stat_part)
+                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, splitk)
   if (out_bf16 && out_f32) SLAMHIP_IGEMM_GO(true, true);
   else if (out_bf16) SLAMHIP_IGEMM_GO(true, false);
   else SLAMHIP_IGEMM_GO(false, true);
@@ -1031,8 +1040,19 @@ int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, flo
   SLAMHIP_REQUIRE(a_mk && b_nk && (out_bf16 || out_f32), SLAMHIP_E_ARG, "gemm_nt: null pointer");
   SLAMHIP_REQUIRE(K % 64 == 0, SLAMHIP_E_SIZE, "gemm_nt: K (%d) must be a multiple of 64", K);
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0) launch_igemm<1, 128>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s);
-  else launch_igemm<1, 64>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s);
+  // few output tiles and a long K (the fully connected layers at small batch): split K over
+  // blockIdx.y so that the weight stream is spread over the chip; float32 output only
+  const int bn = (N % 128 == 0) ? 128 : 64;
+  const long long tiles = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
+  int splitk = 1;
+  if (!out_bf16 && tiles < 256 && K >= 1024) {
+    splitk = (int)((512 + tiles - 1) / tiles);
+    if (splitk > K / 256) splitk = K / 256;      // at least four K-steps per slice
+    if (splitk < 1) splitk = 1;
+  }
+  if (splitk > 1) SLAMHIP_HIP(hipMemsetAsync(out_f32, 0, sizeof(float) * (size_t)M * N, s));
+  if (bn == 128) launch_igemm<1, 128>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s, nullptr, splitk);
+  else launch_igemm<1, 64>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s, nullptr, splitk);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

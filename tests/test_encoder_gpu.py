@@ -281,3 +281,12 @@ def test_conv_with_fused_statistics(ops, B, H, W, C, N):
     z = out.float().reshape(-1, N).double()
     close(sums[0], z.sum(0).float().cpu(), rtol=1e-5, atol=1e-3)
     close(sums[1], (z * z).sum(0).float().cpu(), rtol=1e-5, atol=1e-3)
+
+
+@pytest.mark.parametrize("M,N,K", [(4, 256, 4096), (128, 64, 2048), (3, 6, 1024)])
+def test_gemm_split_k(ops, M, N, K):
+    """Few output tiles and a long K: the float32-only call splits K over workgroups."""
+    a, b = rnd(M, K, seed=50), rnd(N, K, seed=51, scale=0.1)
+    out = torch.full((M, N), 5.0, dtype=torch.float32, device="cuda")
+    ops.gemm_nt(a.cuda().to(BF), b.cuda().to(BF), out_f32=out)
+    close(out, a @ b.t(), rtol=2e-3)
