@@ -202,6 +202,160 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 }
 
 // ---------------------------------------------------------------------------
+// The same implicit GEMM with 256 x 256 tiles for wide layers (N % 256 == 0): eight waves
+// (2 x 4, 128 x 64 outputs each), both operand tiles of a K-step brought from global memory
+// straight into LDS by global_load_lds_dwordx4 (no staging registers, no ds_write), two
+// LDS buffers, one barrier per K-step: the loads of step s + 1 are in flight while the
+// matrix cores work on step s.
+//   LDS image of a tile: [256 rows][64 bf16] with 128-byte rows; a wave-instruction of the
+//   DMA writes 1 KiB = 8 rows.  The 16-byte chunk q of row R is stored at position
+//   q ^ ((R >> 1) & 7) (the loader permutes which global chunk a lane fetches), which makes
+//   the fragment reads (ds_read_b128, 16 rows x one chunk per lane group) conflict-free.
+//   Rows beyond M and taps outside the image fetch a line of zeros.
+// ---------------------------------------------------------------------------
+__device__ __attribute__((aligned(256))) uint4 g_zero_line[16];   // never written: zeros
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* global_void_ptr;
+
+template <int TAPS>
+__global__ void __launch_bounds__(512)
+igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
+                     int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
+                     float* __restrict__ stat_part) {
+  constexpr int TILE_BYTES = 256 * 128;                         // one operand tile of one K-step
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE_BYTES];   // [buffer][A | B]
+
+  const int per_xcd = (total_tiles + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_tiles) return;
+  const int m0 = (work / n_tiles) * 256, n0 = (work % n_tiles) * 256;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int Ktot = TAPS * C;
+
+  // loader: piece P = wave * 4 + j (j = 0..3) covers rows 8P .. 8P + 7; lane -> row 8P + (lane >> 3),
+  // position lane & 7, fetching global chunk position ^ ((row >> 1) & 7)
+  const bf16* a_src[4];
+  const bf16* b_src[4];
+  int a_y[4], a_x[4];
+  bool a_row_ok[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (wave * 4 + j) * 8 + (lane >> 3);
+    const int g = (lane & 7) ^ ((r >> 1) & 7);
+    a_row_ok[j] = m0 + r < M;
+    const int pm = a_row_ok[j] ? m0 + r : M - 1;
+    a_y[j] = a_x[j] = 0;
+    if (TAPS == 9) {
+      const int rem = pm % (H * W);
+      a_y[j] = rem / W;
+      a_x[j] = rem - a_y[j] * W;
+    }
+    a_src[j] = A + (long long)pm * C + g * 8;
+    b_src[j] = Bw + (long long)(n0 + r) * Ktot + g * 8;
+  }
+  const bf16* zero_src = reinterpret_cast<const bf16*>(g_zero_line);
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int ksteps = TAPS * (C / 64);
+  int tap = 0, c0 = 0;   // position of the next tile to request
+
+  // request the tile (tap, c0) into buffer `buf` and advance the position
+#define SLAMHIP_IGEMM256_ISSUE(buf)                                                                  \
+  {                                                                                                  \
+    int dy = 0, dx = 0;                                                                              \
+    if (TAPS == 9) {                                                                                 \
+      const int t = flip ? 8 - tap : tap;                                                            \
+      dy = t / 3 - 1;                                                                                \
+      dx = t - (t / 3) * 3 - 1;                                                                      \
+    }                                                                                                \
+    unsigned char* a_dst = lds + (buf) * 2 * TILE_BYTES + wave * 4096;                               \
+    unsigned char* b_dst = a_dst + TILE_BYTES;                                                       \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
+      bool ok = a_row_ok[j];                                                                         \
+      if (TAPS == 9) ok = ok && (unsigned)(a_y[j] + dy) < (unsigned)H && (unsigned)(a_x[j] + dx) < (unsigned)W; \
+      const bf16* src = ok ? a_src[j] + (long long)(dy * W + dx) * C + c0 : zero_src;                \
+      __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(a_dst + j * 1024), 16, 0, 0); \
+    }                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
+      __builtin_amdgcn_global_load_lds((global_void_ptr)(b_src[j] + tap * C + c0),                   \
+                                       (lds_void_ptr)(b_dst + j * 1024), 16, 0, 0);                  \
+    c0 += 64;                                                                                        \
+    if (c0 == C) { c0 = 0; ++tap; }                                                                  \
+  }
+
+  // fragment addresses (bytes within a tile): row R, chunk q -> R * 128 + ((q ^ ((R >> 1) & 7)) << 4)
+  int a_off[4], b_off[2];
+  const int qh = lane >> 5;   // which 8-element half of a 16-deep MFMA step
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const int R = wm * 128 + i * 32 + (lane & 31); a_off[i] = R * 128; }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { const int R = wn * 64 + j * 32 + (lane & 31); b_off[j] = R * 128; }
+  const int swz = (((lane & 31) >> 1) & 7);   // (R >> 1) & 7: the tile bases are multiples of 32 rows
+
+  SLAMHIP_IGEMM256_ISSUE(0);
+  for (int s = 0; s < ksteps; ++s) {
+    // the only DMA loads in flight are this step's: once they have landed and every wave has
+    // passed the barrier, the tile is complete and the other buffer is no longer being read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (s + 1 < ksteps) SLAMHIP_IGEMM256_ISSUE((s + 1) & 1);
+    const unsigned char* a_tile = lds + (s & 1) * 2 * TILE_BYTES;
+    const unsigned char* b_tile = a_tile + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int chunk = ((kk * 2 + qh) ^ swz) << 4;
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_tile + a_off[i] + chunk);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(b_tile + b_off[j] + chunk);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  }
+#undef SLAMHIP_IGEMM256_ISSUE
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        if (m < M) out_bf16[(long long)m * N + n] = (bf16)acc[i][j][r];
+      }
+  if (stat_part) {   // one record of 2N floats per (256-row tile, wave row)
+    float* part = stat_part + ((long long)(work / n_tiles) * 2 + wm) * 2 * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (float)(bf16)acc[i][j][r];
+          sm += v;
+          sq = __builtin_fmaf(v, v, sq);
+        }
+      store_column_stats(sm, sq, part, n0 + wn * 64 + j * 32 + (lane & 31), N, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient:  dW[tap][ci][co] += sum_p X[pixel(p) + tap][ci] * dY[p][co]
 // (TAPS = 1: dW[ci][co] = X^T dY over the rows).  Both operands sit pixel-major
 // in LDS exactly as they come from HBM; the MFMA fragments (8 consecutive pixels
@@ -965,6 +1119,21 @@ static unsigned int reduce_grid(long long P, int C) {
   return (unsigned int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
+// 256 x 256 tiles: wide layers with enough pixel tiles to fill the chip
+static bool use_igemm256(long long M, int N, const void* out_bf16, const float* out_f32) {
+  static const int mode = [] { const char* e = getenv("SLAMHIP_IGEMM256"); return e ? atoi(e) : 1; }();   // 0 off, 2 always
+  if (mode == 0 || N % 256 != 0 || !out_bf16 || out_f32) return false;
+  return mode == 2 || (M + 255) / 256 * (N / 256) >= 256;     // 2: always (tests)
+}
+
+template <int TAPS>
+static void launch_igemm256(const void* a, const void* b, void* out_bf16, long long M, int N, int C, int H, int W,
+                            int flip, hipStream_t s, float* stat_part) {
+  const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 256, total = m_tiles * n_tiles;
+  hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
+                     (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part);
+}
+
 template <int TAPS, int BN>
 static void launch_igemm(const void* a, const void* b, void* out_bf16, float* out_f32, long long M, int N, int C,
                          int H, int W, int flip, hipStream_t s, float* stat_part = nullptr, int splitk = 1) {
@@ -994,7 +1163,8 @@ int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16
   const long long M = (long long)B * H * W;
   SLAMHIP_REQUIRE(M <= 0x7fffffffLL, SLAMHIP_E_SIZE, "conv3x3_igemm: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
+  if (use_igemm256(M, N, out_bf16, out_f32)) launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, flip, s, nullptr);
+  else if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
   else launch_igemm<9, 64>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
@@ -1027,10 +1197,17 @@ int slamhip_conv3x3_igemm_bf16_stats(const void* act, const void* w_nk, void* ou
                   "conv3x3_igemm_stats: workspace of %zu bytes, need %zu", workspace_bytes,
                   slamhip_conv_stats_workspace_bytes(M, N));
   hipStream_t s = (hipStream_t)stream;
-  if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
-  else launch_igemm<9, 64>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
+  long long records = (M + 127) / 128 * 2;      // one per (128-row tile, wave row) ...
+  if (use_igemm256(M, N, out_bf16, nullptr)) {
+    launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, 0, s, (float*)workspace);
+    records = (M + 255) / 256 * 2;               // ... or per (256-row tile, wave row)
+  } else if (N % 128 == 0) {
+    launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
+  } else {
+    launch_igemm<9, 64>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
+  }
   SLAMHIP_HIP(hipGetLastError());
-  return finish_stats((const float*)workspace, sums2c, (M + 127) / 128 * 2, N, s);
+  return finish_stats((const float*)workspace, sums2c, records, N, s);
 }
 
 int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, float* out_f32, int M, int N, int K,

@@ -290,3 +290,31 @@ def test_gemm_split_k(ops, M, N, K):
     out = torch.full((M, N), 5.0, dtype=torch.float32, device="cuda")
     ops.gemm_nt(a.cuda().to(BF), b.cuda().to(BF), out_f32=out)
     close(out, a @ b.t(), rtol=2e-3)
+
+
+def test_wide_layer_uses_256_tiles(ops):
+    """A layer wide and large enough for the 256 x 256-tile kernel (N % 256 == 0, >= 256 tiles):
+    forward with fused statistics and data gradient against float32 on the CPU."""
+    B, H, W, C, N = 16, 64, 64, 256, 256
+    x = rnd(B, H, W, C, seed=60, scale=0.5).requires_grad_()
+    w = rnd(3, 3, C, N, seed=61, scale=0.02).requires_grad_()
+    y = conv_ref(x, w)
+    dy = rnd(B, H, W, N, seed=62)
+    y.backward(dy)
+    xd, dyd = x.detach().cuda().to(BF), dy.cuda().to(BF)
+    w_fwd, w_dg = torch.empty(N, 9 * C, dtype=BF, device="cuda"), torch.empty(C, 9 * N, dtype=BF, device="cuda")
+    ops.conv_weight_layouts(w.detach().cuda(), w_fwd, w_dg)
+    out = torch.empty(B, H, W, N, dtype=BF, device="cuda")
+    sums = torch.empty(2, N, device="cuda")
+    ws = torch.empty(ops.conv_stats_workspace_bytes(B * H * W, N) // 4, device="cuda")
+    ops.conv3x3_stats(xd, w_fwd, out, sums, ws)
+    close(out, y)
+    z = out.float().reshape(-1, N).double()
+    close(sums[0], z.sum(0).float().cpu(), rtol=1e-5, atol=1e-2)
+    close(sums[1], (z * z).sum(0).float().cpu(), rtol=1e-5, atol=1e-2)
+    out2 = torch.empty_like(out)
+    ops.conv3x3(xd, w_fwd, out_bf16=out2)
+    assert torch.equal(out, out2)
+    dx = torch.empty(B, H, W, C, dtype=BF, device="cuda")
+    ops.conv3x3(dyd, w_dg, out_bf16=dx, flip=True)
+    close(dx, x.grad)
