@@ -279,6 +279,28 @@ int slamhip_sgd_step(float* param, const float* grad, long long n, float lr, flo
 int slamhip_rmsprop_step(float* param, const float* grad, float* ms, long long n, float lr,
                          float decay, float eps, float grad_scale, void* stream);
 
+/* ---- device: recurrent head of the CNN-LSTM trainer ----------------------------
+ * slam/network/lstm_model.py:25-49 - L stacked LSTM cells of n units applied for one
+ * time step to x [B][n], then out = m_top . fc_w + fc_b.  The cell is TensorFlow
+ * 0.x's LSTMCell without peepholes or projection (an un-vendored dependency of the
+ * reference): (i, j, f, o) = split([x, m_prev] . W + b); c = sigmoid(f + forget_bias)
+ * c_prev + sigmoid(i) tanh(j); m = sigmoid(o) tanh(c).  float32, row-major:
+ * W [L][2n][4n], bias [L][4n], fc_w [n][D], fc_b [D]; state_in / state_out
+ * [B][L][2n] with [c, m] per layer (the MultiRNNCell state the reference feeds as
+ * zeros, main/lstm_rgbd.py:60); gates [B][L][4n] receives the activated gates for the
+ * backward pass.  n <= 64, D <= 64. */
+int slamhip_lstm_head_fwd(const float* x, const float* state_in, const float* W, const float* bias,
+                          const float* fc_w, const float* fc_b, float forget_bias, int B, int n, int L,
+                          int D, float* gates, float* state_out, float* out, void* stream);
+/* Gradients of a loss with d loss / d out = d_out [B][D]: d_x [B][n] (flows into the
+ * encoder), dW, dbias, dfc_w, dfc_b (shapes of the parameters, overwritten; batch
+ * sums in row order).  d_pre [B][L][4n] is scratch that receives the gradients at the
+ * gate pre-activations.  No gradient is produced for state_in (a fed constant). */
+int slamhip_lstm_head_bwd(const float* d_out, const float* x, const float* state_in, const float* W,
+                          const float* fc_w, const float* gates, const float* state_out, int B, int n,
+                          int L, int D, float* d_pre, float* d_x, float* dW, float* dbias, float* dfc_w,
+                          float* dfc_b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,7 +307,20 @@ class VGG16Model:
         self._d_out_pad = torch.zeros(self.batch_size, OUT_PAD, dtype=torch.float32, device=self.device)
         return self.loss
 
+    def add_custom_loss(self, loss_and_gradient):
+        """A loss defined on the graph's output outside this class, as the PoseNet trainer
+        does (main/vgg16_posenet.py:16-25, 63): loss_and_gradient(network_output, loss, d_out)
+        fills the [1] loss tensor and d loss / d network_output (d_out may be None)."""
+        self._custom_loss = loss_and_gradient
+        self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._d_out = torch.zeros(self.batch_size, self.output_dim, dtype=torch.float32, device=self.device)
+        self._d_out_pad = torch.zeros(self.batch_size, OUT_PAD, dtype=torch.float32, device=self.device)
+        return self.loss
+
     def compute_loss(self, with_gradient=True):
+        if getattr(self, "_custom_loss", None) is not None:
+            self._custom_loss(self.network_output, self.loss, self._d_out if with_gradient else None)
+            return self.loss
         ops.l2loss(self.network_output, self._ground_truth, self._loss_weight, self.loss,
                    self._d_out if with_gradient else None)
         return self.loss
@@ -372,13 +385,15 @@ class VGG16Model:
                 self.trace[n] = dict(g_out=g_out, dz=dz.clone(), d_in=g.clone() if i else None)
 
     # -------------------------------------------------------------- optimizer
-    def add_optimizer(self):
+    def add_optimizer(self, optimizer=None):
         """Adam (or the optimizer the configuration names) on a learning rate of
         0.01 * 0.1^(global_step // 5) (cnn_model.py:146-160).  Returns the callable that
-        runs one training step and gives back the loss tensor."""
+        runs one training step and gives back the loss tensor.  `optimizer` names the
+        update rule directly, for trainers that do not read it from the configuration
+        (main/vgg16_posenet.py:27-41)."""
         self.global_step = 0
         learning_rate = lambda step: 0.01 * 0.1 ** (step // 5)   # exponential_decay, staircase
-        self._optimizer = self.get_optimizer(learning_rate)
+        self._optimizer = self.get_optimizer(learning_rate) if optimizer is None else _Optimizer(optimizer, learning_rate)
         if self._optimizer.kind == 'AdamOptimizer':
             self._adam_m = torch.zeros_like(self.flat_params)
             self._adam_v = torch.zeros_like(self.flat_params)
@@ -406,12 +421,18 @@ class VGG16Model:
         self.global_step += 1
         self._operands_stale = True
 
-    def train_step(self):
-        """forward, loss, backward, gradient mean over the data-parallel ranks, update."""
+    def set_output_gradient(self, d_output):
+        """d loss / d network_output from a head built on this encoder's output
+        (main/lstm_rgbd.py:71-77), in place of the gradient of the encoder's own loss."""
+        if getattr(self, "_d_out", None) is None:
+            self._d_out = torch.zeros(self.batch_size, self.output_dim, dtype=torch.float32, device=self.device)
+            self._d_out_pad = torch.zeros(self.batch_size, OUT_PAD, dtype=torch.float32, device=self.device)
+        self._d_out.copy_(d_output)
+
+    def backward_with_allreduce(self):
+        """backward(); under torch.distributed the gradient sum over the ranks runs in two
+        buckets, the fully connected one while the convolution gradients are computed."""
         from .. import distributed as dp
-        world = dp.world_size()
-        self.forward()
-        self.compute_loss(with_gradient=True)
         if dp.initialised():
             pending = []
             self.backward(on_fc_done=lambda: pending.append(
@@ -420,7 +441,20 @@ class VGG16Model:
             dp.finish(pending)
         else:
             self.backward()
-        self._apply_gradients(1.0 / world)
+
+    def apply_sgd(self, learning_rate, grad_scale=1.0):
+        """Plain gradient descent on every parameter (the update a head's optimizer applies
+        to the encoder, slam/network/lstm_model.py:63-66)."""
+        ops.sgd_step(self.flat_params, self.flat_grads, learning_rate, grad_scale=grad_scale)
+        self._operands_stale = True
+
+    def train_step(self):
+        """forward, loss, backward, gradient mean over the data-parallel ranks, update."""
+        from .. import distributed as dp
+        self.forward()
+        self.compute_loss(with_gradient=True)
+        self.backward_with_allreduce()
+        self._apply_gradients(1.0 / dp.world_size())
         return self.loss
 
     def start_training(self, max_steps):

@@ -246,3 +246,34 @@ def conv3x3_small_stats(x, w_hwio, out, sums2c, workspace):
     assert _chk(sums2c, F32, "sums").shape == (2, cout) and workspace.is_cuda and workspace.is_contiguous()
     _call("slamhip_conv3x3_small_fwd_stats", capi.ptr(x), capi.ptr(w_hwio), capi.ptr(out), B, H, W, cin, cout,
           capi.ptr(sums2c), capi.ptr(workspace), workspace.numel() * workspace.element_size())
+
+
+def lstm_head_fwd(x, state_in, W, bias, fc_w, fc_b, gates, state_out, out, forget_bias=1.0):
+    """Stack of LSTM cells for one time step + linear output layer (float32)."""
+    B, n = _chk(x, F32, "x").shape
+    L = _chk(W, F32, "W").shape[0]
+    D = _chk(fc_w, F32, "fc_w").shape[1]
+    assert W.shape == (L, 2 * n, 4 * n) and _chk(bias, F32, "bias").shape == (L, 4 * n)
+    assert fc_w.shape == (n, D) and _chk(fc_b, F32, "fc_b").shape == (D,)
+    assert _chk(state_in, F32, "state_in").shape == (B, 2 * n * L)
+    assert _chk(state_out, F32, "state_out").shape == (B, 2 * n * L)
+    assert _chk(gates, F32, "gates").shape == (B, L, 4 * n) and _chk(out, F32, "out").shape == (B, D)
+    _call("slamhip_lstm_head_fwd", capi.ptr(x), capi.ptr(state_in), capi.ptr(W), capi.ptr(bias), capi.ptr(fc_w),
+          capi.ptr(fc_b), float(forget_bias), B, n, L, D, capi.ptr(gates), capi.ptr(state_out), capi.ptr(out))
+
+
+def lstm_head_bwd(d_out, x, state_in, W, fc_w, gates, state_out, d_pre, d_x, dW, dbias, dfc_w, dfc_b):
+    B, n = _chk(x, F32, "x").shape
+    L = _chk(W, F32, "W").shape[0]
+    D = _chk(fc_w, F32, "fc_w").shape[1]
+    assert W.shape == (L, 2 * n, 4 * n) and fc_w.shape == (n, D)
+    assert _chk(d_out, F32, "d_out").shape == (B, D) and _chk(d_x, F32, "d_x").shape == (B, n)
+    for t in (state_in, state_out):
+        assert _chk(t, F32, "state").shape == (B, 2 * n * L)
+    for t in (gates, d_pre):
+        assert _chk(t, F32, "gates").shape == (B, L, 4 * n)
+    assert _chk(dW, F32, "dW").shape == W.shape and _chk(dbias, F32, "dbias").shape == (L, 4 * n)
+    assert _chk(dfc_w, F32, "dfc_w").shape == (n, D) and _chk(dfc_b, F32, "dfc_b").shape == (D,)
+    _call("slamhip_lstm_head_bwd", capi.ptr(d_out), capi.ptr(x), capi.ptr(state_in), capi.ptr(W), capi.ptr(fc_w),
+          capi.ptr(gates), capi.ptr(state_out), B, n, L, D, capi.ptr(d_pre), capi.ptr(d_x), capi.ptr(dW),
+          capi.ptr(dbias), capi.ptr(dfc_w), capi.ptr(dfc_b))

@@ -182,6 +182,91 @@ class SimpleInputProvider:
         return self.seq_dir_map[dirname]['relpos'][offset, :]
 
 
+def read_rgb_image(filepath, image_reader=read_png, rng=np.random):
+    """model_input.py:497-515 - scale so that the smaller side is 256 (output size
+    round(factor * side), order-1 interpolation as resize_bilinear), then a random
+    224 x 224 crop."""
+    rgb_img = np.asarray(image_reader(filepath))
+    width = height = 224
+    factor = 256.0 / min(rgb_img.shape[0], rgb_img.shape[1])
+    rgb_img = resize_bilinear(rgb_img, int(np.round(rgb_img.shape[0] * factor)), int(np.round(rgb_img.shape[1] * factor)))
+    width_start = rng.randint(0, rgb_img.shape[1] - width)
+    height_start = rng.randint(0, rgb_img.shape[0] - height)
+    return rgb_img[height_start:height_start + height, width_start:width_start + width]
+
+
+class PoseNetInputProvider:
+    """Batches of the Cambridge landmarks data (model_input.py:456-495): rows
+    'image x y z qw qx qy qz' of dataset_train.txt in file order, images scaled, cropped
+    and mean-subtracted per batch.  As in the reference the last partial batch and one
+    full batch that would end exactly at the last row are not produced (`index +
+    batch_size < len`)."""
+
+    BASE_DIR = '/usr/data/cvpr_shared/lingni/cambridge_pose_dataset/KingsCollege/'
+
+    def __init__(self, base_dir=None, image_reader=read_png):
+        self.base_dir = self.BASE_DIR if base_dir is None else base_dir
+        self.image_reader = image_reader
+        rows = []
+        with open(os.path.join(self.base_dir, 'dataset_train.txt')) as f:
+            for line in f:
+                fields = line.split()
+                if len(fields) == 8:        # the dataset's three title lines have other counts
+                    rows.append(fields)
+        self.sequence_info = np.array(rows, dtype="str").reshape(-1, 8)
+
+    class PoseNetBatch:
+        pass
+
+    class PoseNetIterator:
+
+        def __init__(self, provider, batch_size):
+            self.provider = provider
+            self.sequence_info = provider.sequence_info
+            self.index = 0
+            self.batch_size = batch_size
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            if self.index + self.batch_size >= len(self.sequence_info):
+                raise StopIteration()
+            batch_info = self.sequence_info[self.index:self.index + self.batch_size]
+            filenames = [os.path.join(self.provider.base_dir, filename) for filename in batch_info[:, 0]]
+            rgb_files = [read_rgb_image(filename, self.provider.image_reader) for filename in filenames]
+            mean = get_mean(rgb_files)
+            batch = PoseNetInputProvider.PoseNetBatch()
+            batch.rgb_files = [rgb_file - mean for rgb_file in rgb_files]
+            batch.groundtruths = batch_info[:, 1:]
+            batch.rgb_filenames = filenames
+            self.index += self.batch_size
+            return batch
+
+        next = __next__
+
+    def sequence_batch_itr(self, batch_size):
+        return PoseNetInputProvider.PoseNetIterator(self, batch_size)
+
+
+def write_synthetic_posenet_dataset(base_dir, n_images=6, height=270, width=480, seed=0):
+    """A Cambridge-landmarks-shaped directory (seq1/*.png + dataset_train.txt) of synthetic
+    images and poses, for runs without the dataset."""
+    from PIL import Image
+    from ..utils import synthetic as syn
+    os.makedirs(os.path.join(base_dir, "seq1"), exist_ok=True)
+    rgb = syn.rgb_frames(n_images, height, width, seed=seed, kind="smooth")
+    poses = syn.pose_pairs(n_images, seed=seed)[:, 1]       # tx ty tz qx qy qz qw
+    with open(os.path.join(base_dir, "dataset_train.txt"), "w") as f:
+        f.write("Visual Landmark Dataset V1\nImageFile, Camera Position [X Y Z W P Q R]\n\n")
+        for i in range(n_images):
+            name = "seq1/frame%05d.png" % i
+            Image.fromarray(rgb[i]).save(os.path.join(base_dir, name))
+            t, q = poses[i, :3], poses[i, 3:]
+            f.write("%s %s\n" % (name, " ".join("%.6f" % v for v in (t[0], t[1], t[2], q[3], q[0], q[1], q[2]))))
+    return base_dir
+
+
 def get_simple_input_provider(filename_provider, base_data_dir=None):
     """model_input.py:528-529."""
     return SimpleInputProvider(filename_provider, base_data_dir=base_data_dir)

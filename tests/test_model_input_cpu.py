@@ -3,6 +3,8 @@ against the oracle's restatement of model_input.py:384-396, per-batch mean
 subtraction against get_mean (:517-522, golden-pinned in test_oracle_golden),
 the Python-2 integer depth scaling, iterator semantics.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -65,3 +67,28 @@ def test_resize_is_identity_at_same_size_and_exact_on_ramps():
     ramp = np.tile(np.arange(8.0)[None, :, None], (4, 1, 1))
     out = mi.resize_bilinear(ramp, 4, 4)
     np.testing.assert_allclose(out[0, :, 0], [0.5, 2.5, 4.5, 6.5])
+
+
+def test_posenet_input_provider(tmp_path):
+    """model_input.py:456-515 - rows of dataset_train.txt in order, scale-to-256 + 224 crop,
+    per-batch mean subtraction, and the reference's end condition (index + batch < len)."""
+    from slam_amd.network import model_input as mi
+    d = mi.write_synthetic_posenet_dataset(str(tmp_path / "kings"), n_images=5, height=270, width=480)
+    provider = mi.PoseNetInputProvider(d)
+    assert provider.sequence_info.shape == (5, 8)                 # the three title lines are skipped
+    batches = list(provider.sequence_batch_itr(2))
+    assert len(batches) == 2                                      # rows 0-1 and 2-3; 4 + 2 >= 5 ends the pass
+    b = batches[0]
+    assert [os.path.basename(f) for f in b.rgb_filenames] == ["frame00000.png", "frame00001.png"]
+    assert b.groundtruths.shape == (2, 7) and all(img.shape == (224, 224, 3) for img in b.rgb_files)
+    np.testing.assert_allclose(mi.get_mean(b.rgb_files), 0.0, atol=1e-9)
+    assert len(list(provider.sequence_batch_itr(5))) == 0         # 0 + 5 < 5 is false
+    # scaling: the smaller side becomes 256, the other round(side * factor)
+    class Fixed:
+        @staticmethod
+        def randint(lo, hi):
+            return hi - 1
+    img = mi.read_rgb_image(os.path.join(d, "seq1", "frame00000.png"), rng=Fixed)
+    full = mi.resize_bilinear(mi.read_png(os.path.join(d, "seq1", "frame00000.png")), 256, int(np.round(480 * 256.0 / 270)))
+    assert full.shape[:2] == (256, 455)
+    np.testing.assert_array_equal(img, full[31:255, 230:454])
