@@ -270,6 +270,15 @@ int slamhip_prep_rgbd(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, 
                       float* out_f32, void* out_bf16, double* mean4, void* workspace,
                       size_t workspace_bytes, void* stream);
 
+/* slam/network/model_input.py:185-217 - the same preparation as the reference's
+ * in-graph reader does it: depth decoded to 8 bits (tf.image.decode_png's default
+ * dtype keeps the upper byte of a 16-bit sample), both images resized with
+ * TensorFlow 0.x's bilinear rule (source coordinate = index * in / out, float32),
+ * then depth * 255 / max(resized depth) per frame, 4-channel concat, no mean
+ * subtraction.  Same workspace as slamhip_prep_rgbd. */
+int slamhip_prep_rgbd_tf(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, int Ws, int Ho, int Wo,
+                         float* out_f32, void* workspace, size_t workspace_bytes, void* stream);
+
 /* cnn_model.py:167-170 - the other two optimizers the configuration may name:
  * tf.train.GradientDescentOptimizer (p -= lr g) and tf.train.RMSPropOptimizer
  * with momentum 0 (ms = decay ms + (1-decay) g^2; p -= lr g / sqrt(ms + eps);

@@ -70,6 +70,7 @@ SIGNATURES = {
     "slamhip_bias_relu_bwd": ([_c_void_p] * 4 + [ctypes.c_longlong, _c_int, _c_void_p], _c_int),
     "slamhip_prep_rgbd_workspace_bytes": ([_c_int], ctypes.c_size_t),
     "slamhip_prep_rgbd": ([_c_void_p, _c_void_p] + [_c_int] * 5 + [_c_void_p] * 4 + [ctypes.c_size_t, _c_void_p], _c_int),
+    "slamhip_prep_rgbd_tf": ([_c_void_p, _c_void_p] + [_c_int] * 5 + [_c_void_p] * 2 + [ctypes.c_size_t, _c_void_p], _c_int),
     "slamhip_sgd_step": ([_c_void_p, _c_void_p, ctypes.c_longlong, ctypes.c_float, ctypes.c_float, _c_void_p], _c_int),
     "slamhip_rmsprop_step": ([_c_void_p] * 3 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_void_p], _c_int),
     "slamhip_lstm_head_fwd": ([_c_void_p] * 6 + [ctypes.c_float] + [_c_int] * 4 + [_c_void_p] * 4, _c_int),

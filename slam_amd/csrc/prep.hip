@@ -101,6 +101,50 @@ subtract_mean_kernel(float* __restrict__ out, bf16_t* __restrict__ out_bf16, con
   }
 }
 
+// The in-graph variant (model_input.py:185-217): the depth PNG decoded to 8 bits (the
+// upper byte of the 16-bit sample), both images resized with TensorFlow 0.x's bilinear
+// rule (source coordinate = index * in / out, no half-pixel shift, float32 lerp), then
+// depth * 255 / max(resized depth); no mean subtraction.  Pass 1 writes the resized
+// frame and the per-frame maximum (non-negative floats order like their bit patterns).
+__global__ void __launch_bounds__(256)
+resize_rgbd_tf_kernel(const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, float* __restrict__ out,
+                      unsigned int* __restrict__ dmax_bits, int B, int Hs, int Ws, int Ho, int Wo) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * Ho * Wo) return;
+  const int xo = (int)(idx % Wo);
+  const int yo = (int)((idx / Wo) % Ho);
+  const int b = (int)(idx / ((long long)Wo * Ho));
+  const float in_y = (float)yo * ((float)Hs / (float)Ho), in_x = (float)xo * ((float)Ws / (float)Wo);
+  const int y0 = (int)floorf(in_y), x0 = (int)floorf(in_x);
+  const int y1 = min((int)ceilf(in_y), Hs - 1), x1 = min((int)ceilf(in_x), Ws - 1);
+  const float fy = in_y - (float)y0, fx = in_x - (float)x0;
+  const long long base = (long long)b * Hs * Ws;
+  const long long o00 = base + (long long)y0 * Ws + x0, o01 = base + (long long)y0 * Ws + x1;
+  const long long o10 = base + (long long)y1 * Ws + x0, o11 = base + (long long)y1 * Ws + x1;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    float a, bq, cq, e;
+    if (c < 3) {
+      a = rgb[3 * o00 + c]; bq = rgb[3 * o01 + c]; cq = rgb[3 * o10 + c]; e = rgb[3 * o11 + c];
+    } else {
+      a = (float)(depth[o00] >> 8); bq = (float)(depth[o01] >> 8);
+      cq = (float)(depth[o10] >> 8); e = (float)(depth[o11] >> 8);
+    }
+    const float top = a + (bq - a) * fx, bot = cq + (e - cq) * fx;
+    const float v = top + (bot - top) * fy;
+    out[idx * 4 + c] = v;
+    if (c == 3) atomicMax(&dmax_bits[b], __float_as_uint(fmaxf(v, 0.0f)));
+  }
+}
+
+__global__ void __launch_bounds__(256)
+scale_depth_tf_kernel(float* __restrict__ out, const unsigned int* __restrict__ dmax_bits, long long total, int hw) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float mx = __uint_as_float(dmax_bits[i / hw]);
+  out[4 * i + 3] = out[4 * i + 3] * 255.0f / mx;     // an all-zero depth image gives NaN, as in the reference
+}
+
 }  // namespace slamhip
 
 using namespace slamhip;
@@ -130,6 +174,27 @@ int slamhip_prep_rgbd(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, 
                      sums, B, Hs, Ws, Ho, Wo);
   hipLaunchKernelGGL(subtract_mean_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_f32,
                      (bf16_t*)out_bf16, sums, mean4, total, 1.0 / (double)total);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_prep_rgbd_tf(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, int Ws, int Ho, int Wo,
+                         float* out_f32, void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, SLAMHIP_E_ARG, "prep_rgbd_tf: bad shape");
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(rgb && depth && out_f32 && workspace, SLAMHIP_E_ARG, "prep_rgbd_tf: null pointer");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_prep_rgbd_workspace_bytes(B), SLAMHIP_E_SIZE,
+                  "prep_rgbd_tf: workspace of %zu bytes, need %zu", workspace_bytes, slamhip_prep_rgbd_workspace_bytes(B));
+  SLAMHIP_REQUIRE((long long)Hs * Ws <= 0x7fffffffLL && (long long)B * Ho * Wo <= 0x7fffffffLL, SLAMHIP_E_SIZE,
+                  "prep_rgbd_tf: too many pixels");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned int* dmax = (unsigned int*)((char*)workspace + 64);
+  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, slamhip_prep_rgbd_workspace_bytes(B), s));
+  const long long total = (long long)B * Ho * Wo;
+  hipLaunchKernelGGL(resize_rgbd_tf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rgb, depth, out_f32,
+                     dmax, B, Hs, Ws, Ho, Wo);
+  hipLaunchKernelGGL(scale_depth_tf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_f32, dmax, total,
+                     Ho * Wo);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -69,6 +69,96 @@ def absolute_twist_labels(gt_rows):
     return twist
 
 
+class QueuedInputProvider:
+    """The queue-fed provider (model_input.py:126-319): per training sequence a cyclic,
+    unshuffled queue of (rgb file, depth file, twist) over a window of at most 300
+    frames, read through the in-graph reader's arithmetic (8-bit depth, TensorFlow
+    bilinear resize, depth * 255 / max; slam_amd.network.prep.rgbd_batch_tf).
+
+    The reference hands back graph tensors that every session.run refills; here
+    get_training_batch() returns the GPU tensors once and run() refills them with the
+    next element of every queue."""
+
+    BASE_DATA_DIR = '/home/sanjeev/data/'
+    FX = [517.3, 520.9, 535.4]
+    FY = [516.5, 521.0, 539.2]
+    CX = [318.6, 325.1, 320.1]
+    CY = [255.3, 249.7, 247.6]
+    FACTOR = 1
+
+    def __init__(self, base_data_dir=None, image_reader=read_png, config_provider=None):
+        from .model_config import get_config_provider
+        self.config_provider = config_provider or get_config_provider()
+        base = self.BASE_DATA_DIR if base_data_dir is None else base_data_dir
+        self.training_filenames = [os.path.join(base, name) for name in self.config_provider.training_filenames()]
+        self.batch_size = len(self.training_filenames)
+        self.image_reader = image_reader
+        self._queues = None
+
+    def get_training_batch(self):
+        """-> (images_batch, groundtruth_batch): per sequence one float32 GPU tensor
+        [224,224,4] and one [1,1,6] (model_input.py:154-180), filled with the first element."""
+        import torch
+        dev = torch.device("cuda", torch.cuda.current_device())
+        sequence_length = 300
+        self._queues, self._images, self._twists = [], [], []
+        for filename in self.training_filenames:
+            associations = np.loadtxt(os.path.join(filename, "associate.txt"), dtype="str", unpack=False)
+            groundtruth = np.loadtxt(os.path.join(filename, "groundtruth.txt"), dtype="str", unpack=False)
+            twist, rgb_filepaths, depth_filepaths = self._get_data(associations, groundtruth, sequence_length)
+            self._queues.append(dict(rgb=[os.path.join(filename, f) for f in rgb_filepaths],
+                                     depth=[os.path.join(filename, f) for f in depth_filepaths],
+                                     twist=np.asarray(twist, np.float64), pos=0))
+            self._images.append(torch.zeros(224, 224, 4, dtype=torch.float32, device=dev))
+            self._twists.append(torch.zeros(1, 1, 6, dtype=torch.float32, device=dev))
+        self.run()
+        return self._images, self._twists
+
+    def run(self):
+        """Next element of every queue into the tensors get_training_batch() returned
+        (the queues wrap around, slice_input_producer without an epoch limit)."""
+        for q, image, twist in zip(self._queues, self._images, self._twists):
+            i = q["pos"] % len(q["rgb"])
+            q["pos"] += 1
+            self.read_rgbd_data((q["rgb"][i], q["depth"][i], q["twist"][i]), image, twist)
+
+    def read_rgbd_data(self, input_queue, image=None, twist=None):
+        """(rgb path, depth path, twist[6]) -> (float32 [224,224,4], float32 [1,1,6]) GPU
+        tensors (model_input.py:185-217)."""
+        import torch
+        from . import prep
+        dev = torch.device("cuda", torch.cuda.current_device())
+        rgb = torch.from_numpy(np.ascontiguousarray(self.image_reader(input_queue[0]), np.uint8)[None]).to(dev)
+        depth = torch.from_numpy(np.ascontiguousarray(self.image_reader(input_queue[1])).astype(np.uint16)[None]).to(dev)
+        out = prep.rgbd_batch_tf(rgb, depth, (224, 224), out=None if image is None else image.view(1, 224, 224, 4))
+        tw = torch.from_numpy(np.asarray(input_queue[2], np.float32).reshape(1, 1, 6)).to(dev)
+        if twist is not None:
+            twist.copy_(tw)
+        return out[0], tw
+
+    def get_batch_size(self):
+        return self.batch_size
+
+    def _point_cloud(self, depth_image, dataset_int):
+        """model_input.py:222-229 indexes the cloud with u * v (sic), which overwrites most
+        rows; the back-projection itself is the one of preprocess.geometry._point_cloud,
+        which this returns (row u + v * W, compacted)."""
+        from ..preprocess import geometry
+        return geometry._point_cloud(depth_image, dataset_int)
+
+    def _backtransform_pointcloud(self, pointcloud, dataset_int):
+        from ..preprocess import geometry
+        return geometry._backtransform_pointcloud(pointcloud, dataset_int)
+
+    def _get_data(self, associations, groundtruth, sequence_length, dynamic_drop=0.0, static_drop=1, rng=np.random):
+        """model_input.py:243-319: as preprocess.geometry._get_data with the clamped twist.
+        The reference's drop branch cannot run (undefined names at :269, :279); here it
+        runs the overlap test of preprocess.geometry._get_data."""
+        from ..preprocess import geometry
+        return geometry._get_data(associations, groundtruth, sequence_length, dynamic_drop, static_drop,
+                                  read_depth=self.image_reader, rng=rng, clamp=True)
+
+
 class SimpleInputProvider:
 
     class SequenceBatch:
@@ -265,6 +355,17 @@ def write_synthetic_posenet_dataset(base_dir, n_images=6, height=270, width=480,
             t, q = poses[i, :3], poses[i, 3:]
             f.write("%s %s\n" % (name, " ".join("%.6f" % v for v in (t[0], t[1], t[2], q[3], q[0], q[1], q[2]))))
     return base_dir
+
+
+_queued_input_provider = None
+
+
+def get_queued_input_provider(base_data_dir=None):
+    """model_input.py:524-526 (created on first use instead of at import)."""
+    global _queued_input_provider
+    if _queued_input_provider is None:
+        _queued_input_provider = QueuedInputProvider(base_data_dir)
+    return _queued_input_provider
 
 
 def get_simple_input_provider(filename_provider, base_data_dir=None):

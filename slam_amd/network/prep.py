@@ -31,3 +31,25 @@ def rgbd_batch(rgb, depth, out_hw=(224, 224), out=None, out_bf16=None):
                                      capi.ptr(mean), capi.ptr(ws), ws.numel(), capi.current_stream()),
                "slamhip_prep_rgbd")
     return out, mean
+
+
+def rgbd_batch_tf(rgb, depth, out_hw=(224, 224), out=None):
+    """The reference's in-graph reader (slam/network/model_input.py:185-217) for a batch of
+    raw frames: 8-bit depth (upper byte), TensorFlow 0.x bilinear resize, depth * 255 /
+    max per frame, no mean subtraction.  -> float32 [B,Ho,Wo,4]."""
+    if not (rgb.is_cuda and depth.is_cuda and rgb.dtype == torch.uint8 and depth.dtype == torch.uint16):
+        raise ValueError("rgb must be a uint8 and depth a uint16 GPU tensor")
+    rgb, depth = rgb.contiguous(), depth.contiguous()
+    B, H, W, C = rgb.shape
+    if C != 3 or depth.shape != (B, H, W):
+        raise ValueError("rgb [B,H,W,3] and depth [B,H,W] expected, got %s %s" % (tuple(rgb.shape), tuple(depth.shape)))
+    Ho, Wo = out_hw
+    if out is None:
+        out = torch.empty(B, Ho, Wo, 4, dtype=torch.float32, device=rgb.device)
+    elif out.shape != (B, Ho, Wo, 4) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous float32 [B,Ho,Wo,4] tensor")
+    lib = capi.load()
+    ws = torch.empty(max(lib.slamhip_prep_rgbd_workspace_bytes(B), 8), dtype=torch.uint8, device=rgb.device)
+    capi.check(lib.slamhip_prep_rgbd_tf(capi.ptr(rgb), capi.ptr(depth), B, H, W, Ho, Wo, capi.ptr(out), capi.ptr(ws),
+                                        ws.numel(), capi.current_stream()), "slamhip_prep_rgbd_tf")
+    return out

@@ -88,10 +88,12 @@ def _overlap(backtransform, dim):
 
 
 def _get_data(associations, groundtruth, sequence_length, dynamic_drop=0.0, static_drop=1,
-              read_depth=None, rng=np.random):
+              read_depth=None, rng=np.random, clamp=False):
     """test_import.py:178-246.  Labels on the host C path, the overlap test of the
     dynamic drop on the GPU with the previous frame's cloud kept resident.
-    `read_depth(path) -> uint16 [H,W]` replaces the reference's PNG read (:204)."""
+    `read_depth(path) -> uint16 [H,W]` replaces the reference's PNG read (:204).
+    clamp=True takes the twist with the clamped arccos argument, the variant the
+    queued provider's copy of this function calls (model_input.py:46-54, 243-319)."""
     associations = associations[0::static_drop]
     rgb_filepaths = associations[:, 1]
     depth_filepaths = associations[:, 3]
@@ -110,7 +112,7 @@ def _get_data(associations, groundtruth, sequence_length, dynamic_drop=0.0, stat
             d = torch.from_numpy(np.ascontiguousarray(read_depth(associations[i, 3]), dtype=np.uint16)[None]).to(_device())
             cloud = fp.backproject(d, K, FACTOR, torch.float64)
         if i > 0:
-            rel, tw = fp.pose_batch(gt7[old:old + 1], gt7[i:i + 1])
+            rel, tw = fp.pose_batch(gt7[old:old + 1], gt7[i:i + 1], clamp)
             if drop:
                 xyz, valid0 = cloud_old
                 out = fp.reproject(xyz, torch.from_numpy(rel).to(xyz.device), K, (640, 480), valid0=valid0,
