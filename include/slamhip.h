@@ -310,6 +310,49 @@ int slamhip_lstm_head_bwd(const float* d_out, const float* x, const float* state
                           int L, int D, float* d_pre, float* d_x, float* dW, float* dbias, float* dfc_w,
                           float* dfc_b, void* stream);
 
+/* ---- device: layer kernels of the GoogLeNet / PoseNet encoder --------------------
+ * slam/network/google_net.py:14-215 builds on kaffe.tensorflow.network.Network (an
+ * un-vendored dependency): conv = tf.nn.conv2d SAME + bias + ReLU, max_pool / avg_pool
+ * SAME unless stated, lrn = tf.nn.local_response_normalization, concat on channels,
+ * fc = x.W + b.  SAME follows TensorFlow: out = ceil(in / stride), total padding
+ * max((out-1)*stride + k - in, 0), the smaller half in front.  Activations are NHWC
+ * bfloat16; the GEMMs are slamhip_gemm_nt_bf16 / slamhip_wgrad_bf16 on the im2col matrix.
+ * Every *_add entry ADDS into its destination (a tensor that feeds several branches
+ * collects their gradients; the caller zeroes the buffer once per step). */
+int slamhip_conv_out_shape(int H, int W, int KH, int KW, int stride, int same, int* Ho, int* Wo);
+/* col [B*Ho*Wo][Kp] bfloat16, K = KH*KW*C in (ky, kx, c) order, Kp = K rounded up to 64
+ * (zero filled); SAME padding; C % 8 == 0. */
+int slamhip_im2col_bf16(const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride,
+                        void* stream);
+/* dx [B,H,W,C] += the transpose of the gather above applied to dcol [B*Ho*Wo][Kp]. */
+int slamhip_col2im_add_bf16(const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW,
+                            int stride, void* stream);
+/* Epilogue of a convolution / fc layer into a channel slice: y[m*ld + off + n] =
+ * act(z[m*Np + n] + bias[n]) for n < N (z float32 [M][Np]); y_bf16 and/or y_f32.  And its
+ * backward: dz [M][Np] bfloat16 = dy[m*ld + off + n] (dy_bf16 or dy_f32) gated by y > 0
+ * when relu, zero for n >= N; dbias [Np] float32 = column sums (overwritten). */
+int slamhip_bias_act_slice_fwd(const float* z, const float* bias, void* y_bf16, float* y_f32, long long M,
+                               int N, int Np, int ld, int off, int relu, void* stream);
+int slamhip_bias_act_slice_bwd(const void* dy_bf16, const float* dy_f32, const void* y_bf16, void* dz,
+                               float* dbias, long long M, int N, int Np, int ld, int off, int relu,
+                               void* stream);
+/* K x K pooling with the given stride, SAME (same != 0) or VALID; is_max selects max or
+ * average (average over the cells inside the image).  Backward adds into dx; a max
+ * window's gradient goes to its first maximum in (ky, kx) order. */
+int slamhip_pool_fwd(const void* x, void* y, int B, int H, int W, int C, int K, int stride, int same,
+                     int is_max, void* stream);
+int slamhip_pool_bwd_add(const void* x, const void* dy, void* dx, int B, int H, int W, int C, int K,
+                         int stride, int same, int is_max, void* stream);
+/* y = x / (bias + alpha * sum_{|j-c| <= radius} x_j^2)^beta over the channel axis of
+ * x [P][C] bfloat16 (google_net.py:18,21: radius 2, alpha 2e-5, beta 0.75, bias 1). */
+int slamhip_lrn_fwd(const void* x, void* y, long long P, int C, int radius, float bias, float alpha,
+                    float beta, void* stream);
+int slamhip_lrn_bwd_add(const void* x, const void* dy, void* dx, long long P, int C, int radius, float bias,
+                        float alpha, float beta, void* stream);
+/* float32 [P][C] -> bfloat16 [P][Cp] with zero channels C..Cp-1 (the 3- or 4-channel
+ * network input widened to the 8 channels im2col works in). */
+int slamhip_pad_cast_bf16(const float* src, void* dst, long long P, int C, int Cp, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,6 +75,16 @@ SIGNATURES = {
     "slamhip_rmsprop_step": ([_c_void_p] * 3 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_void_p], _c_int),
     "slamhip_lstm_head_fwd": ([_c_void_p] * 6 + [ctypes.c_float] + [_c_int] * 4 + [_c_void_p] * 4, _c_int),
     "slamhip_lstm_head_bwd": ([_c_void_p] * 7 + [_c_int] * 4 + [_c_void_p] * 7, _c_int),
+    "slamhip_conv_out_shape": ([_c_int] * 6 + [_c_void_p] * 2, _c_int),
+    "slamhip_im2col_bf16": ([_c_void_p] * 2 + [_c_int] * 7 + [_c_void_p], _c_int),
+    "slamhip_col2im_add_bf16": ([_c_void_p] * 2 + [_c_int] * 7 + [_c_void_p], _c_int),
+    "slamhip_bias_act_slice_fwd": ([_c_void_p] * 4 + [ctypes.c_longlong] + [_c_int] * 5 + [_c_void_p], _c_int),
+    "slamhip_bias_act_slice_bwd": ([_c_void_p] * 5 + [ctypes.c_longlong] + [_c_int] * 5 + [_c_void_p], _c_int),
+    "slamhip_pool_fwd": ([_c_void_p] * 2 + [_c_int] * 8 + [_c_void_p], _c_int),
+    "slamhip_pool_bwd_add": ([_c_void_p] * 3 + [_c_int] * 8 + [_c_void_p], _c_int),
+    "slamhip_lrn_fwd": ([_c_void_p] * 2 + [ctypes.c_longlong, _c_int, _c_int] + [ctypes.c_float] * 3 + [_c_void_p], _c_int),
+    "slamhip_lrn_bwd_add": ([_c_void_p] * 3 + [ctypes.c_longlong, _c_int, _c_int] + [ctypes.c_float] * 3 + [_c_void_p], _c_int),
+    "slamhip_pad_cast_bf16": ([_c_void_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_adam_step": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float,
                                                                                           _c_void_p], _c_int),
 }

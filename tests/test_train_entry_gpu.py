@@ -107,3 +107,30 @@ def test_vgg16_posenet_entry_point_runs(tmp_path):
     assert m._optimizer.kind == 'AdamOptimizer'
     step()
     assert np.isfinite(float(loss_t))
+
+
+def test_google_net_trainers_run(tmp_path, monkeypatch):
+    """slam/main/posenet.py, posenet_noLRN.py, posenet_rgbd.py end to end on synthetic data."""
+    from slam_amd.main import posenet, posenet_noLRN, posenet_rgbd
+    from slam_amd.network import model_config as mc
+    loss = posenet.main(["--synthetic", str(tmp_path / "kings"), "--synthetic-items", "5", "--epochs", "1",
+                         "--batch-size", "2", "--base-dir", str(tmp_path / "p1")])
+    assert np.isfinite(loss)
+    saved = torch.load(str(tmp_path / "p1" / "checkpoints" / "learned_weights.pt"), weights_only=True)
+    assert saved["conv1_7x7_s2/weights"].shape == (7, 7, 3, 64) and saved["output3/weights"].shape == (1, 1, 1024, 7)
+    assert saved["inception_4b_fc1/weights"].shape == (1, 1, 5 * 5 * 128, 1024) and int(saved["global_step"]) == 2
+    loss = posenet_noLRN.main(["--synthetic", str(tmp_path / "kings"), "--epochs", "1", "--base-dir", str(tmp_path / "p2")])
+    assert np.isfinite(loss)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = json.load(open(os.path.join(root, "resources", "model.config")))
+    cfg["train"]["slam_files"] = ["freiburg1_xyz", "freiburg1_rpy"]
+    p = tmp_path / "model.config"
+    p.write_text(json.dumps(cfg))
+    monkeypatch.setenv("SLAM_MODEL_CONFIG", str(p))
+    monkeypatch.setattr(mc, "_config_provider", None)
+    loss = posenet_rgbd.main(["--synthetic", str(tmp_path / "tum"), "--synthetic-items", "4", "--epochs", "1",
+                              "--batch-size", "2", "--sequence-length", "2", "--base-dir", str(tmp_path / "p3")])
+    assert np.isfinite(loss)
+    saved = torch.load(str(tmp_path / "p3" / "checkpoints" / "learned_weights.pt"), weights_only=True)
+    assert saved["conv1_7x7_s2/weights"].shape == (7, 7, 4, 64) and saved["output1/biases"].shape == (6,)
+    monkeypatch.setattr(mc, "_config_provider", None)
