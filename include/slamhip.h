@@ -58,6 +58,12 @@ int slamhip_quat_to_transformation(const float* gt7, int n, double* T4x4);
 /* test_import.py:80-86 - [R^T, -R^T t; 0 1]. */
 int slamhip_inverse_trans(const double* T4x4, int n, double* inv4x4);
 
+/* slam/preprocess/import_data.py:12-42 - [x, y, z, rotation vector] of an absolute pose
+ * [tx ty tz qx qy qz qw] (float64 in, as the reference casts the text row): Euler angles
+ * from the quaternion components in the reference's order, rotation matrix from the
+ * angles, w = theta / (2 sin theta) * (R - R^T)v. */
+int slamhip_absolute_position(const double* gt7, int n, double* pos6);
+
 /* test_import.py:50-77 (clamp=0) / slam/network/model_input.py:46-76 (clamp=1):
  * SO(3) log + the reference's translation solve; guards give zeros, an exact
  * identity rotation gives NaN. */

@@ -16,6 +16,7 @@ Line ranges used (1-based, inclusive):
   slam/network/model_input.py     14-106  pose maths (clamp variant)
                                   113-119 224x224 _overlap
                                   517-522 get_mean
+  slam/preprocess/import_data.py  12-42   _absolute_position
 The two Python-2 `print` statements inside those ranges are blanked before exec.
 
 Run:  python oracle/make_golden.py     (re-creates every fixture deterministically)
@@ -272,6 +273,17 @@ def gen_get_data(ti):
     np.savez_compressed(os.path.join(OUT, "get_data.npz"), **out)
 
 
+def gen_abs_position():
+    """slam/preprocess/import_data.py:12-42 (_absolute_position) on seeded poses."""
+    ns = {"np": np}
+    exec(compile(_load_ranges("slam/preprocess/import_data.py", [(12, 42)]), "<reference:import_data>", "exec"), ns)
+    rs = np.random.RandomState(31)
+    gt = np.stack([np.concatenate([rs.uniform(-2, 2, 3), rand_unit_quat(rs)]) for _ in range(16)])
+    gt[-1, 3:] = [0.0, 0.0, 0.0, 1.0]        # identity orientation as the reference reads it: NaN / inf angles
+    pos = np.stack([ns["_absolute_position"](row) for row in gt])
+    np.savez_compressed(os.path.join(OUT, "abs_position.npz"), gt=gt, pos=pos)
+
+
 def main():
     warnings.simplefilter("ignore")
     if not os.path.isdir(REF):
@@ -284,6 +296,7 @@ def main():
     gen_geometry_full(ti, rel)
     gen_mean(mi)
     gen_get_data(ti)
+    gen_abs_position()
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -134,6 +134,25 @@ def relative_pose(T_old, T_new):
     return np.dot(inverse_trans(T_old), T_new)
 
 
+def absolute_position(gt7):
+    """slam/preprocess/import_data.py:12-42 - [x, y, z, rotation vector]; the quaternion
+    columns (qx, qy, qz, qw) are read as q[0..3] in Euler formulas of a (w, x, y, z)
+    quaternion (sic), then the rotation matrix is rebuilt from the angles."""
+    g = np.asarray(gt7, dtype=np.float64)
+    q0, q1, q2, q3 = g[3], g[4], g[5], g[6]
+    phi = np.arctan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2))
+    theta = np.arcsin(2 * (q0 * q2 - q3 * q1))
+    psi = np.arctan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3))
+    ct, st, cp, sp, cs, ss = np.cos(theta), np.sin(theta), np.cos(phi), np.sin(phi), np.cos(psi), np.sin(psi)
+    R = np.array([[ct * cp, ss * st * cp - cs * sp, cs * st * cp + ss * sp],
+                  [ct * sp, ss * st * sp + cs * cp, cs * st * sp - ss * cp],
+                  [-st, ss * ct, cs * ct]])
+    w_abs = np.arccos((np.trace(R) - 1) / 2)
+    f = 1 / (2 * np.sin(w_abs))
+    w = np.array([f * (R[2, 1] - R[1, 2]) * w_abs, f * (R[0, 2] - R[2, 0]) * w_abs, f * (R[1, 0] - R[0, 1]) * w_abs])
+    return np.concatenate((g[0:3], w))
+
+
 def trans_to_twist(T, clamp=False):
     """test_import.py:50-77 (clamp=False) / model_input.py:46-76 (clamp=True).
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     "slamhip_version": ([], _c_int),
     "slamhip_quat_to_transformation": ([_c_void_p, _c_int, _c_void_p], _c_int),
     "slamhip_inverse_trans": ([_c_void_p, _c_int, _c_void_p], _c_int),
+    "slamhip_absolute_position": ([_c_void_p, _c_int, _c_void_p], _c_int),
     "slamhip_trans_to_twist": ([_c_void_p, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_twist_to_trans": ([_c_void_p, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_pose_batch": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p, _c_void_p], _c_int),

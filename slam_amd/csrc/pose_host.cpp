@@ -188,6 +188,33 @@ static void twist_to_T(const double* tw, int guard, double* T) {
   }
 }
 
+// slam/preprocess/import_data.py:12-42 - position + rotation vector of an absolute pose,
+// the rotation rebuilt from Euler angles of the quaternion READ AS (q0..q3) = (qx, qy, qz, qw)
+// in the formulas of a (w, x, y, z) quaternion (sic), operations in the reference's order.
+static void absolute_position(const double* g, double* out) {
+  const double q0 = g[3], q1 = g[4], q2 = g[5], q3 = g[6];
+  const double phi = atan2(2 * (q0 * q1 + q2 * q3), 1 - 2 * (q1 * q1 + q2 * q2));
+  const double theta = asin(2 * (q0 * q2 - q3 * q1));
+  const double psi = atan2(2 * (q0 * q3 + q1 * q2), 1 - 2 * (q2 * q2 + q3 * q3));
+  const double ct = cos(theta), st = sin(theta), cp = cos(phi), sp = sin(phi), cs = cos(psi), ss = sin(psi);
+  double R[3][3];
+  R[0][0] = ct * cp;
+  R[1][0] = ct * sp;
+  R[2][0] = -st;
+  R[0][1] = ss * st * cp - cs * sp;
+  R[1][1] = ss * st * sp + cs * cp;
+  R[2][1] = ss * ct;
+  R[0][2] = cs * st * cp + ss * sp;
+  R[1][2] = cs * st * sp - ss * cp;
+  R[2][2] = cs * ct;
+  const double w_abs = acos(((R[0][0] + R[1][1] + R[2][2]) - 1) / 2);
+  const double f = 1 / (2 * sin(w_abs));
+  out[0] = g[0]; out[1] = g[1]; out[2] = g[2];
+  out[3] = f * (R[2][1] - R[1][2]) * w_abs;
+  out[4] = f * (R[0][2] - R[2][0]) * w_abs;
+  out[5] = f * (R[1][0] - R[0][1]) * w_abs;
+}
+
 }  // namespace slamhip
 
 using namespace slamhip;
@@ -233,6 +260,12 @@ int slamhip_pose_batch(const float* gt7_a, const float* gt7_b, int n, int clamp,
     if (rel4x4) std::memcpy(rel4x4 + 16 * i, rel, sizeof(rel));
     if (twist6) T_to_twist(rel, clamp, twist6 + 6 * i);
   }
+  return SLAMHIP_OK;
+}
+
+int slamhip_absolute_position(const double* gt7, int n, double* pos6) {
+  SLAMHIP_REQUIRE(n >= 0 && (n == 0 || (gt7 && pos6)), SLAMHIP_E_ARG, "absolute_position: bad argument");
+  for (int i = 0; i < n; ++i) absolute_position(gt7 + 7 * i, pos6 + 6 * i);
   return SLAMHIP_OK;
 }
 

@@ -251,6 +251,15 @@ def inverse_trans_batch(T):
     return inv
 
 
+def absolute_position_batch(gt7):
+    """[n,7] float64 poses -> [n,6] (slam/preprocess/import_data.py:12-42), on the host."""
+    g = np.ascontiguousarray(np.asarray(gt7, dtype=np.float64).reshape(-1, 7))
+    out = np.empty((g.shape[0], 6))
+    capi.check(capi.load().slamhip_absolute_position(g.ctypes.data, g.shape[0], out.ctypes.data),
+               "slamhip_absolute_position")
+    return out
+
+
 def trans_to_twist_batch(T, clamp=False):
     T = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(-1, 4, 4))
     tw = np.empty((T.shape[0], 6))

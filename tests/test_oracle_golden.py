@@ -162,3 +162,20 @@ def test_losses():
     o7, g7 = rs.normal(size=(3, 7)), rs.normal(size=(3, 7))
     want = np.sum((o7[:, :3] - g7[:, :3]) ** 2) + 1100 * np.sum((o7[:, 3:] - g7[:, 3:]) ** 2)
     assert abs(so.posenet_loss(o7, g7) - want) < 1e-9
+
+
+def test_absolute_position_golden(golden_dir):
+    """slam/preprocess/import_data.py:12-42: the restatement and the library's host function
+    against the reference function's own outputs."""
+    g = _load(golden_dir, "abs_position.npz")
+    want = g["pos"]
+    got = np.stack([so.absolute_position(row) for row in g["gt"]])
+    np.testing.assert_allclose(got, want, rtol=1e-12, atol=1e-14, equal_nan=True)
+    from slam_amd import frame_pairs as fp
+    from slam_amd.preprocess import import_data
+    np.testing.assert_allclose(fp.absolute_position_batch(g["gt"]), want, rtol=1e-11, atol=1e-13, equal_nan=True)
+    np.testing.assert_allclose(import_data._absolute_position(g["gt"][0]), want[0], rtol=1e-11, atol=1e-13)
+    rgb = np.arange(48 * 64 * 3, dtype=np.uint8).reshape(48, 64, 3)
+    depth = (np.arange(48 * 64).reshape(48, 64, 1) * 7 + 500).astype(np.uint16)
+    img = import_data._image_preprocessing(rgb, depth)
+    assert img.shape == (224, 224, 4) and abs(img[..., 3].max() - 255.0) < 1.0 and abs(img[..., 3].min()) < 1.0
