@@ -209,6 +209,18 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
                         const float* beta, float* red2c, void* dz, long long P, int C, float eps,
                         void* stream);
 
+/* The two calls above fused with the 2x2 stride-2 max-pool that follows the last
+ * layer of every block (cnn_model.py:40,45,50,56,62).  Forward: z [B,H,W,C] -> y (same
+ * shape) and pooled [B,H/2,W/2,C] in one pass.  Backward: dpooled [B,H/2,W/2,C] is
+ * the gradient at the pooled tensor; it goes to each window's first maximum of y
+ * (recomputed from z), through the ReLU gate and the batch-norm backward into dz
+ * [B,H,W,C]; red2c as above.  H and W even. */
+int slamhip_bn_relu_pool_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta,
+                             void* y, void* pooled, int B, int H, int W, int C, float eps, void* stream);
+int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* sums2c, const float* gamma,
+                             const float* beta, float* red2c, void* dz, int B, int H, int W, int C,
+                             float eps, void* stream);
+
 /* cnn_model.py:123,74 / cnn_model_noBN.py (bias_add + relu) - y = act(z + bias) on a float32
  * [M][N] product (relu=0: the linear output layer); backward: dz = dy * (y>0),
  * dbias[n] = sum_m dz. */

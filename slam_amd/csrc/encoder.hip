@@ -969,6 +969,168 @@ maxpool2_bwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ y, cons
 }
 
 // ---------------------------------------------------------------------------
+// batch-norm + ReLU fused with the 2x2 max-pool that follows it (the last layer of
+// every block, cnn_model.py:37-62).  One thread owns a pooling window x 8 channels.
+// Forward: z -> y (kept for the next block's filter gradient) and pooled in one pass.
+// Backward: the pooled gradient goes to the window's first maximum of y (row-major
+// order, as maxpool2_bwd_kernel) and y is recomputed from z with the forward's own
+// operations, so neither y nor an upsampled gradient tensor is read or written.
+// ---------------------------------------------------------------------------
+struct PoolWindow {
+  long long o[4];     // bf16x8 indices of the four pixels
+};
+__device__ __forceinline__ PoolWindow pool_window(long long pp, int c8, int H, int W, int C8) {
+  const int Wo = W >> 1, Ho = H >> 1;
+  const int xo = (int)(pp % Wo);
+  const long long r = pp / Wo;
+  const int yo = (int)(r % Ho);
+  const long long b = r / Ho;
+  PoolWindow w;
+  w.o[0] = ((b * H + 2 * yo) * W + 2 * xo) * C8 + c8;
+  w.o[1] = w.o[0] + C8;
+  w.o[2] = w.o[0] + (long long)W * C8;
+  w.o[3] = w.o[2] + C8;
+  return w;
+}
+
+__global__ void __launch_bounds__(256)
+bn_relu_pool_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ sums, const float* __restrict__ gamma,
+                        const float* __restrict__ beta, bf16* __restrict__ y, bf16* __restrict__ pooled,
+                        long long total8, int H, int W, int C, float inv_count, float eps) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // over pooled pixels x C/8
+  if (i >= total8) return;
+  const int C8 = C >> 3;
+  const int c8 = (int)(i % C8), c0 = c8 * 8;
+  float mean[8], r[8], bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    mean[j] = sums[c0 + j] * inv_count;
+    const float var = fmaxf(sums[C + c0 + j] * inv_count - mean[j] * mean[j], 0.0f);
+    r[j] = gamma[c0 + j] * rsqrtf(var + eps);
+    bet[j] = beta[c0 + j];
+  }
+  const long long stride = (long long)gridDim.x * blockDim.x;          // a multiple of C/8
+  for (; i < total8; i += stride) {
+    const PoolWindow w = pool_window(i / C8, c8, H, W, C8);
+    bf16x8 v[4], best;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const bf16x8*>(z)[w.o[q]];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      bf16x8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[q][j] - mean[j], r[j], bet[j]), 0.0f);
+        best[j] = (q == 0 || (float)o[j] > (float)best[j]) ? o[j] : best[j];
+      }
+      reinterpret_cast<bf16x8*>(y)[w.o[q]] = o;
+    }
+    reinterpret_cast<bf16x8*>(pooled)[i] = best;
+  }
+}
+
+// out[c] += sum g, out[C + c] += sum g * xhat over the pixels that won their pooling window
+__global__ void __launch_bounds__(256)
+bn_pool_bwd_reduce_kernel(const bf16* __restrict__ dpooled, const bf16* __restrict__ z, const float* __restrict__ sums,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
+                          long long PP, int H, int W, int C, float inv_count, float eps) {
+  __shared__ float part[256 * 17];
+  const int groups = C >> 3;
+  const int rlanes = 256 / groups;
+  const int gcol = threadIdx.x % groups, rlane = threadIdx.x / groups;
+  float s0[8], s1[8], mean[8], rstd[8], gam[8], bet[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { s0[j] = 0.f; s1[j] = 0.f; mean[j] = 0.f; rstd[j] = 0.f; gam[j] = 0.f; bet[j] = 0.f; }
+  if (rlane < rlanes) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = gcol * 8 + j;
+      mean[j] = sums[c] * inv_count;
+      rstd[j] = rsqrtf(fmaxf(sums[C + c] * inv_count - mean[j] * mean[j], 0.0f) + eps);
+      gam[j] = gamma[c] * rstd[j];
+      bet[j] = beta[c];
+    }
+    const long long stride = (long long)gridDim.x * rlanes;
+    for (long long pp = (long long)blockIdx.x * rlanes + rlane; pp < PP; pp += stride) {
+      const PoolWindow w = pool_window(pp, gcol, H, W, groups);
+      const bf16x8 g = reinterpret_cast<const bf16x8*>(dpooled)[pp * groups + gcol];
+      bf16x8 v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const bf16x8*>(z)[w.o[q]];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float best = 0.0f, dbest = 0.0f;         // y of the winner and its z - mean
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float d = (float)v[q][j] - mean[j];
+          const float yq = (float)(bf16)fmaxf(__builtin_fmaf(d, gam[j], bet[j]), 0.0f);
+          if (q == 0 || yq > best) { best = yq; dbest = d; }
+        }
+        const float ge = best > 0.0f ? (float)g[j] : 0.0f;
+        s0[j] += ge;
+        s1[j] = __builtin_fmaf(ge, dbest * rstd[j], s1[j]);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { part[threadIdx.x * 17 + j] = s0[j]; part[threadIdx.x * 17 + 8 + j] = s1[j]; }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 16 * groups; t += 256) {
+    const int gc = t >> 4, k = t & 15;
+    float acc = 0.f;
+    for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
+    atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+bn_pool_bwd_apply_kernel(const bf16* __restrict__ dpooled, const bf16* __restrict__ z, const float* __restrict__ sums,
+                         const float* __restrict__ red, const float* __restrict__ gamma,
+                         const float* __restrict__ beta, bf16* __restrict__ dz, long long total8, int H, int W, int C,
+                         float inv_count, float eps) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;     // over pooled pixels x C/8
+  if (i >= total8) return;
+  const int C8 = C >> 3;
+  const int c8 = (int)(i % C8), c0 = c8 * 8;
+  float mean[8], r[8], bet[8], k1[8], k2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int c = c0 + j;
+    mean[j] = sums[c] * inv_count;
+    const float var = fmaxf(sums[C + c] * inv_count - mean[j] * mean[j], 0.0f);
+    const float rstd = rsqrtf(var + eps);
+    r[j] = gamma[c] * rstd;
+    bet[j] = beta[c];
+    k1[j] = red[c] * inv_count;
+    k2[j] = rstd * (red[C + c] * inv_count);
+  }
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (; i < total8; i += stride) {
+    const PoolWindow w = pool_window(i / C8, c8, H, W, C8);
+    const bf16x8 g = reinterpret_cast<const bf16x8*>(dpooled)[i];
+    bf16x8 v[4], o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = reinterpret_cast<const bf16x8*>(z)[w.o[q]];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float d[4], best = 0.0f;
+      int win = 0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        d[q] = (float)v[q][j] - mean[j];
+        const float yq = (float)(bf16)fmaxf(__builtin_fmaf(d[q], r[j], bet[j]), 0.0f);
+        if (q == 0 || yq > best) { best = yq; win = q; }
+      }
+      const float ge = best > 0.0f ? (float)g[j] : 0.0f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q][j] = (bf16)(r[j] * (((q == win ? ge : 0.0f) - k1[j]) - d[q] * k2[j]));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) reinterpret_cast<bf16x8*>(dz)[w.o[q]] = o[q];
+  }
+}
+
+// ---------------------------------------------------------------------------
 // casts / re-layouts of the parameters
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1385,6 +1547,38 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_pool_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta, void* y,
+                             void* pooled, int B, int H, int W, int C, float eps, void* stream) {
+  SLAMHIP_REQUIRE(z && sums2c && gamma && beta && y && pooled && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 &&
+                      C > 0 && C % 8 == 0,
+                  SLAMHIP_E_ARG, "bn_relu_pool_fwd: bad argument (even height and width, channels % 8 == 0)");
+  const long long P = (long long)B * H * W, total8 = P / 4 * (C / 8);
+  hipLaunchKernelGGL(bn_relu_pool_fwd_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16*)z, sums2c, gamma, beta, (bf16*)y, (bf16*)pooled, total8, H, W, C, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* sums2c, const float* gamma,
+                             const float* beta, float* red2c, void* dz, int B, int H, int W, int C, float eps,
+                             void* stream) {
+  SLAMHIP_REQUIRE(dpooled && z && sums2c && gamma && beta && red2c && dz && B > 0 && H > 0 && W > 0 && H % 2 == 0 &&
+                      W % 2 == 0 && C > 0 && C % 64 == 0 && C <= 2048,
+                  SLAMHIP_E_ARG, "bn_relu_pool_bwd: bad argument (even height and width, channels % 64 == 0, <= 2048)");
+  const long long P = (long long)B * H * W, PP = P / 4;
+  SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_pool_bwd: too many pixels");
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(reduce_grid(PP, C)), dim3(256), 0, s, (const bf16*)dpooled,
+                     (const bf16*)z, sums2c, gamma, beta, red2c, PP, H, W, C, 1.0f / (float)P, eps);
+  const long long total8 = PP * (C / 8);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s,
+                     (const bf16*)dpooled, (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, H, W, C,
+                     1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -273,6 +273,10 @@ class VGG16Model:
                 else:
                     ops.conv3x3_stats(h, self._w_fwd[n], a["z"], a["sums"], self._stats_ws)
                 bn = self.params[n + "/bn"]
+                if a["pool"]:       # normalisation, ReLU and the block's max-pool in one pass
+                    ops.bn_relu_pool(a["z"], a["sums"], bn[1], bn[0], a["y"], a["pooled"], self.epsilon)
+                    h = a["pooled"]
+                    continue
                 ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)
             elif i == 0:
                 ops.conv3x3_small(h, self.params[n + "/weights"], a["z"])
@@ -362,15 +366,18 @@ class VGG16Model:
             a = self._act[i]
             n = a["name"]
             g_out = g.clone() if self.trace is not None else None
-            if a["pool"]:
-                dy = self._buf(("dy", a["y"].shape), a["y"])
-                ops.maxpool2_bwd(a["y"], a["pooled"], g, dy)
-                g = dy
             dz = self._buf(("dz", a["z"].shape), a["z"])
             if self.batch_norm:
                 bn = self.params[n + "/bn"]
-                ops.bn_relu_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
+                if a["pool"]:   # pool backward + ReLU gate + batch-norm backward, no upsampled gradient tensor
+                    ops.bn_relu_pool_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
+                else:
+                    ops.bn_relu_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
             else:
+                if a["pool"]:
+                    dy = self._buf(("dy", a["y"].shape), a["y"])
+                    ops.maxpool2_bwd(a["y"], a["pooled"], g, dy)
+                    g = dy
                 ops.bias_relu_bwd(g, a["y"], dz, self.grads[n + "/biases"])
             if i == 0:
                 ops.conv3x3_small_wgrad(self._x, dz, self.grads[n + "/weights"])

@@ -120,6 +120,29 @@ def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps):
           capi.ptr(red2c), capi.ptr(dz), P, C, float(eps))
 
 
+def bn_relu_pool(z, sums2c, gamma, beta, y, pooled, eps):
+    """bn_relu and the 2x2 max-pool after it in one pass: y (like z) and pooled [B,H/2,W/2,C]."""
+    B, H, W, C = _chk(z, BF16, "z").shape
+    assert H % 2 == 0 and W % 2 == 0 and C % 8 == 0
+    assert _chk(y, BF16, "y").shape == z.shape and _chk(pooled, BF16, "pooled").shape == (B, H // 2, W // 2, C)
+    assert _chk(sums2c, F32, "sums").shape == (2, C)
+    assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
+    _call("slamhip_bn_relu_pool_fwd", capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y),
+          capi.ptr(pooled), B, H, W, C, float(eps))
+
+
+def bn_relu_pool_bwd(dpooled, z, sums2c, gamma, beta, red2c, dz, eps):
+    """Max-pool backward, ReLU gate and batch-norm backward in one step: the pooled gradient
+    [B,H/2,W/2,C] -> dz (like z); red2c as bn_relu_bwd."""
+    B, H, W, C = _chk(z, BF16, "z").shape
+    assert H % 2 == 0 and W % 2 == 0 and C % 64 == 0
+    assert _chk(dpooled, BF16, "dpooled").shape == (B, H // 2, W // 2, C) and _chk(dz, BF16, "dz").shape == z.shape
+    assert _chk(red2c, F32, "red").shape == (2, C) and _chk(sums2c, F32, "sums").shape == (2, C)
+    assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
+    _call("slamhip_bn_relu_pool_bwd", capi.ptr(dpooled), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta),
+          capi.ptr(red2c), capi.ptr(dz), B, H, W, C, float(eps))
+
+
 def bias_act(z, bias, y_bf16=None, y_f32=None, relu=True):
     M, N = _chk(z, F32, "z").shape
     assert _chk(bias, F32, "bias").shape == (N,)

@@ -318,3 +318,36 @@ def test_wide_layer_uses_256_tiles(ops):
     dx = torch.empty(B, H, W, C, dtype=BF, device="cuda")
     ops.conv3x3(dyd, w_dg, out_bf16=dx, flip=True)
     close(dx, x.grad)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 64), (3, 14, 14, 512), (1, 6, 4, 192)])
+def test_fused_bn_relu_pool_matches_the_separate_kernels(B, H, W, C):
+    """Normalisation + ReLU + 2x2 max-pool in one pass, and pool backward + gate + batch-norm
+    backward in one step, against the separate kernels (identical forward bits; the backward
+    differs only by the summation order of the two channel reductions)."""
+    from slam_amd.network import encoder_ops as ops
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(B * H + C)
+    z = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+    z[0, :2, :2, :8] = z[0, 0, 0, :8]                      # a window of equal values: the first one wins
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    sums = torch.empty(2, C, device=dev)
+    ops.channel_stats(z, sums)
+    y_ref, y = torch.empty_like(z), torch.empty_like(z)
+    pooled_ref = torch.empty(B, H // 2, W // 2, C, dtype=torch.bfloat16, device=dev)
+    pooled = torch.empty_like(pooled_ref)
+    ops.bn_relu(z, sums, gamma, beta, y_ref, 1e-3)
+    ops.maxpool2(y_ref, pooled_ref)
+    ops.bn_relu_pool(z, sums, gamma, beta, y, pooled, 1e-3)
+    assert torch.equal(y, y_ref) and torch.equal(pooled, pooled_ref)
+    dp = torch.randn(B, H // 2, W // 2, C, generator=g).to(dev).to(torch.bfloat16)
+    dy = torch.empty_like(z)
+    ops.maxpool2_bwd(y_ref, pooled_ref, dp, dy)
+    red_ref, red = torch.empty(2, C, device=dev), torch.empty(2, C, device=dev)
+    dz_ref, dz = torch.empty_like(z), torch.empty_like(z)
+    ops.bn_relu_bwd(dy, z, sums, gamma, beta, red_ref, dz_ref, 1e-3)
+    ops.bn_relu_pool_bwd(dp, z, sums, gamma, beta, red, dz, 1e-3)
+    np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    a, b = dz.float().cpu().numpy(), dz_ref.float().cpu().numpy()
+    assert np.abs(a - b).max() <= 0.02 * np.abs(b).max() and (a != b).mean() < 0.02
