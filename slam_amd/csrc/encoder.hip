@@ -54,7 +54,7 @@ template <int TAPS, int BN, bool WRITE_BF16, bool WRITE_F32>
 __global__ void __launch_bounds__(256)
 igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
                   float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip, int n_tiles,
-                  int total_tiles, float* __restrict__ stat_part, int splitk) {
+                  int total_tiles, float* __restrict__ stat_part, int splitk, int m_tile0) {
   constexpr int BM = 128;
   constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
   constexpr int NB = BN / 32;                 // B loader passes: 8 threads (16 B each) cover one 64-element row
@@ -68,7 +68,7 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
   const int per_xcd = (total_tiles + 7) >> 3;
   const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (work >= total_tiles) return;
-  const int m0 = (work / n_tiles) * BM, n0 = (work % n_tiles) * BN;
+  const int m0 = (m_tile0 + work / n_tiles) * BM, n0 = (work % n_tiles) * BN;   // m_tile0: first pixel tile of this launch
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -218,18 +218,18 @@ __device__ __attribute__((aligned(256))) uint4 g_zero_line[16];   // never writt
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
 
-template <int TAPS>
+template <int TAPS, bool PINGPONG>
 __global__ void __launch_bounds__(512)
 igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
                      int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
-                     float* __restrict__ stat_part) {
+                     float* __restrict__ stat_part, int m_tile0) {
   constexpr int TILE_BYTES = 256 * 128;                         // one operand tile of one K-step
   __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE_BYTES];   // [buffer][A | B]
 
   const int per_xcd = (total_tiles + 7) >> 3;
   const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (work >= total_tiles) return;
-  const int m0 = (work / n_tiles) * 256, n0 = (work % n_tiles) * 256;
+  const int m0 = (m_tile0 + work / n_tiles) * 256, n0 = (work % n_tiles) * 256;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
@@ -302,6 +302,109 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
   for (int j = 0; j < 2; ++j) { const int R = wn * 64 + j * 32 + (lane & 31); b_off[j] = R * 128; }
   const int swz = (((lane & 31) >> 1) & 7);   // (R >> 1) & 7: the tile bases are multiples of 32 rows
 
+  // two of the eight DMA loads of a tile: parts 0, 1 = operand A pieces 0-1, 2-3; parts 2, 3 = operand B
+#define SLAMHIP_IGEMM256_PART(buf, part)                                                             \
+  {                                                                                                  \
+    unsigned char* a_dst = lds + (buf) * 2 * TILE_BYTES + wave * 4096;                               \
+    unsigned char* b_dst = a_dst + TILE_BYTES;                                                       \
+    if ((part) < 2) {                                                                                \
+      int dy = 0, dx = 0;                                                                            \
+      if (TAPS == 9) {                                                                               \
+        const int t = flip ? 8 - tap : tap;                                                          \
+        dy = t / 3 - 1;                                                                              \
+        dx = t - (t / 3) * 3 - 1;                                                                    \
+      }                                                                                              \
+      _Pragma("unroll") for (int j = 2 * (part); j < 2 * (part) + 2; ++j) {                          \
+        bool ok = a_row_ok[j];                                                                       \
+        if (TAPS == 9) ok = ok && (unsigned)(a_y[j] + dy) < (unsigned)H && (unsigned)(a_x[j] + dx) < (unsigned)W; \
+        const bf16* src = ok ? a_src[j] + (long long)(dy * W + dx) * C + c0 : zero_src;              \
+        __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(a_dst + j * 1024), 16, 0, 0); \
+      }                                                                                              \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int j = 2 * (part) - 4; j < 2 * (part) - 2; ++j)                        \
+        __builtin_amdgcn_global_load_lds((global_void_ptr)(b_src[j] + tap * C + c0),                 \
+                                         (lds_void_ptr)(b_dst + j * 1024), 16, 0, 0);                \
+    }                                                                                                \
+  }
+#define SLAMHIP_IGEMM256_ADVANCE() \
+  {                                \
+    c0 += 64;                      \
+    if (c0 == C) { c0 = 0; ++tap; } \
+  }
+
+  if constexpr (PINGPONG) {
+    // The two wave rows (wm = 0 / 1, one wave of each per SIMD) run half a phase apart: while one
+    // row's eight MFMAs of a quadrant occupy the matrix cores, the other row reads its next
+    // fragments from LDS and issues its share of the next tile's DMA loads.  Every section ends
+    // in a raw s_barrier, so the two rows alternate strictly; each wave executes the same
+    // number of barriers (the extra one in front for row 1, behind for row 0).
+    //   quadrants of a wave's 128 x 64 outputs per tile: (rows 0-63, cols 0-31), (0-63, 32-63),
+    //   (64-127, 32-63), (64-127, 0-31): each phase reloads only what changed.
+    // A load section waits for its own LDS reads (and, in the last phase of a tile, for its DMA
+    // loads of the next tile) BEFORE its barrier: a buffer is re-filled only after every read of
+    // it has returned, and read only after every wave's loads into it have landed.
+#define SLAMHIP_PP_SECTION_END()                          \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      \
+  __builtin_amdgcn_sched_barrier(0);                      \
+  __builtin_amdgcn_s_barrier();                           \
+  __builtin_amdgcn_sched_barrier(0);
+#define SLAMHIP_PP_LOAD_A(ih)                                                                         \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                  \
+    const int chunk = ((kk * 2 + qh) ^ swz) << 4;                                                     \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+      af[i][kk] = *reinterpret_cast<const bf16x8*>(a_tile + a_off[(ih) * 2 + i] + chunk);             \
+  }
+#define SLAMHIP_PP_LOAD_B(dst, j)                                                                     \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+    dst[kk] = *reinterpret_cast<const bf16x8*>(b_tile + b_off[j] + ((((kk * 2 + qh) ^ swz)) << 4));
+#define SLAMHIP_PP_MFMA(ih, j, bsrc)                                                                  \
+  __builtin_amdgcn_s_setprio(1);                                                                      \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
+      acc[(ih) * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bsrc[kk], acc[(ih) * 2 + i][j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  __builtin_amdgcn_sched_barrier(0);
+
+    SLAMHIP_IGEMM256_PART(0, 0);
+    SLAMHIP_IGEMM256_PART(0, 1);
+    SLAMHIP_IGEMM256_PART(0, 2);
+    SLAMHIP_IGEMM256_PART(0, 3);
+    SLAMHIP_IGEMM256_ADVANCE();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    bf16x8 af[2][4], bq0[4], bq1[4];
+    for (int s = 0; s < ksteps; ++s) {
+      const unsigned char* a_tile = lds + (s & 1) * 2 * TILE_BYTES;
+      const unsigned char* b_tile = a_tile + TILE_BYTES;
+      const bool more = s + 1 < ksteps;
+      const int nbuf = (s + 1) & 1;
+      SLAMHIP_PP_LOAD_A(0);
+      SLAMHIP_PP_LOAD_B(bq0, 0);
+      if (more) { SLAMHIP_IGEMM256_PART(nbuf, 0); SLAMHIP_IGEMM256_PART(nbuf, 1); }
+      SLAMHIP_PP_SECTION_END();
+      SLAMHIP_PP_MFMA(0, 0, bq0);
+      SLAMHIP_PP_LOAD_B(bq1, 1);
+      if (more) SLAMHIP_IGEMM256_PART(nbuf, 2);
+      SLAMHIP_PP_SECTION_END();
+      SLAMHIP_PP_MFMA(0, 1, bq1);
+      SLAMHIP_PP_LOAD_A(1);
+      if (more) { SLAMHIP_IGEMM256_PART(nbuf, 3); SLAMHIP_IGEMM256_ADVANCE(); }
+      SLAMHIP_PP_SECTION_END();
+      SLAMHIP_PP_MFMA(1, 1, bq1);
+      SLAMHIP_PP_LOAD_B(bq0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      SLAMHIP_PP_SECTION_END();
+      SLAMHIP_PP_MFMA(1, 0, bq0);
+    }
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+#undef SLAMHIP_PP_SECTION_END
+#undef SLAMHIP_PP_LOAD_A
+#undef SLAMHIP_PP_LOAD_B
+#undef SLAMHIP_PP_MFMA
+  } else {
   SLAMHIP_IGEMM256_ISSUE(0);
   for (int s = 0; s < ksteps; ++s) {
     // the only DMA loads in flight are this step's: once they have landed and every wave has
@@ -325,7 +428,10 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   }
+  }
 #undef SLAMHIP_IGEMM256_ISSUE
+#undef SLAMHIP_IGEMM256_PART
+#undef SLAMHIP_IGEMM256_ADVANCE
 
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -1290,24 +1396,67 @@ static bool use_igemm256(long long M, int N, const void* out_bf16, const float* 
 
 template <int TAPS>
 static void launch_igemm256(const void* a, const void* b, void* out_bf16, long long M, int N, int C, int H, int W,
-                            int flip, hipStream_t s, float* stat_part) {
-  const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 256, total = m_tiles * n_tiles;
-  hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
-                     (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part);
+                            int flip, hipStream_t s, float* stat_part, int m_tile0 = 0, int m_tiles = -1) {
+  if (m_tiles < 0) m_tiles = (int)((M + 255) / 256);
+  const int n_tiles = N / 256, total = m_tiles * n_tiles;
+  static const bool pingpong = [] { const char* e = getenv("SLAMHIP_IGEMM256_PINGPONG"); return e ? atoi(e) != 0 : false; }();
+  if (pingpong)
+    hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS, true>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
+                       (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
+  else
+    hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS, false>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
+                       (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
 }
 
 template <int TAPS, int BN>
 static void launch_igemm(const void* a, const void* b, void* out_bf16, float* out_f32, long long M, int N, int C,
-                         int H, int W, int flip, hipStream_t s, float* stat_part = nullptr, int splitk = 1) {
-  const int m_tiles = (int)((M + 127) / 128), n_tiles = (N + BN - 1) / BN, total = m_tiles * n_tiles;
+                         int H, int W, int flip, hipStream_t s, float* stat_part = nullptr, int splitk = 1,
+                         int m_tile0 = 0, int m_tiles = -1) {
+  if (m_tiles < 0) m_tiles = (int)((M + 127) / 128);
+  const int n_tiles = (N + BN - 1) / BN, total = m_tiles * n_tiles;
   const dim3 grid((total + 7) / 8 * 8, splitk), block(256);
 #define SLAMHIP_IGEMM_GO(WB, WF)                                                                                 \
   hipLaunchKernelGGL((igemm_bf16_kernel<TAPS, BN, WB, WF>), grid, block, 0, s, (const bf16*)a, (const bf16*)b, \
-                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, splitk)
+                     (bf16*)out_bf16, out_f32, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, splitk, m_tile0)
   if (out_bf16 && out_f32) SLAMHIP_IGEMM_GO(true, true);
   else if (out_bf16) SLAMHIP_IGEMM_GO(true, false);
   else SLAMHIP_IGEMM_GO(false, true);
 #undef SLAMHIP_IGEMM_GO
+}
+
+// A 3x3 convolution (or its data gradient) with the tile sizes that fit it; returns the number
+// of statistics records written when stat_part is given.  One 256 x 256 workgroup occupies a
+// compute unit, so the 256-tile kernel runs in rounds of one tile per compute unit; when the
+// last round would be mostly empty, only the full rounds go to it and the remaining pixel rows
+// to the 128-tile kernel (whose records follow the first kernel's).
+static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf16, float* out_f32, long long M, int N,
+                                int C, int H, int W, int flip, hipStream_t s, float* stat_part) {
+  if (use_igemm256(M, N, out_bf16, out_f32)) {
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+      return n;
+    }();
+    static const int hybrid = [] { const char* e = getenv("SLAMHIP_IGEMM256_HYBRID"); return e ? atoi(e) : 1; }();
+    const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 256;
+    const long long total = (long long)m_tiles * n_tiles;
+    const long long rem = total % cus;
+    int m_big = m_tiles;
+    if (hybrid && total > cus && rem != 0 && rem * 4 < cus) m_big = (int)((total - rem) / n_tiles);
+    launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, flip, s, stat_part, 0, m_big);
+    long long records = 2LL * m_big;
+    if (m_big < m_tiles) {
+      const int m_small = (int)((M - 256LL * m_big + 127) / 128);
+      launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, flip, s,
+                           stat_part ? stat_part + records * 2 * N : nullptr, 1, 2 * m_big, m_small);
+      records += 2LL * m_small;
+    }
+    return records;
+  }
+  if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s, stat_part);
+  else launch_igemm<9, 64>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s, stat_part);
+  return (M + 127) / 128 * 2;
 }
 
 }  // namespace slamhip
@@ -1325,9 +1474,7 @@ int slamhip_conv3x3_igemm_bf16(const void* act, const void* w_nk, void* out_bf16
   const long long M = (long long)B * H * W;
   SLAMHIP_REQUIRE(M <= 0x7fffffffLL, SLAMHIP_E_SIZE, "conv3x3_igemm: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  if (use_igemm256(M, N, out_bf16, out_f32)) launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, flip, s, nullptr);
-  else if (N % 128 == 0) launch_igemm<9, 128>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
-  else launch_igemm<9, 64>(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s);
+  launch_conv3x3(act, w_nk, out_bf16, out_f32, M, N, C, H, W, flip, s, nullptr);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -1359,15 +1506,8 @@ int slamhip_conv3x3_igemm_bf16_stats(const void* act, const void* w_nk, void* ou
                   "conv3x3_igemm_stats: workspace of %zu bytes, need %zu", workspace_bytes,
                   slamhip_conv_stats_workspace_bytes(M, N));
   hipStream_t s = (hipStream_t)stream;
-  long long records = (M + 127) / 128 * 2;      // one per (128-row tile, wave row) ...
-  if (use_igemm256(M, N, out_bf16, nullptr)) {
-    launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, 0, s, (float*)workspace);
-    records = (M + 255) / 256 * 2;               // ... or per (256-row tile, wave row)
-  } else if (N % 128 == 0) {
-    launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
-  } else {
-    launch_igemm<9, 64>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
-  }
+  // one record per (pixel tile, wave row) of whichever kernels ran
+  const long long records = launch_conv3x3(act, w_nk, out_bf16, nullptr, M, N, C, H, W, 0, s, (float*)workspace);
   SLAMHIP_HIP(hipGetLastError());
   return finish_stats((const float*)workspace, sums2c, records, N, s);
 }

@@ -292,10 +292,13 @@ def test_gemm_split_k(ops, M, N, K):
     close(out, a @ b.t(), rtol=2e-3)
 
 
-def test_wide_layer_uses_256_tiles(ops):
+@pytest.mark.parametrize("B", [16, 17])
+def test_wide_layer_uses_256_tiles(ops, B):
     """A layer wide and large enough for the 256 x 256-tile kernel (N % 256 == 0, >= 256 tiles):
-    forward with fused statistics and data gradient against float32 on the CPU."""
-    B, H, W, C, N = 16, 64, 64, 256, 256
+    forward with fused statistics and data gradient against float32 on the CPU.  B = 16 gives
+    exactly one tile per compute unit; B = 17 leaves 16 tiles over, which go to the 128-tile
+    kernel (pixel-tile offset, statistics records behind the first kernel's)."""
+    H, W, C, N = 64, 64, 256, 256
     x = rnd(B, H, W, C, seed=60, scale=0.5).requires_grad_()
     w = rnd(3, 3, C, N, seed=61, scale=0.02).requires_grad_()
     y = conv_ref(x, w)
