@@ -1554,8 +1554,11 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
     const char* e = getenv("SLAMHIP_WGRAD_BLOCKS");     // tuning knob
     return e ? atoll(e) : 2048LL;
   }();
-  long long splitk = (target_blocks + tiles - 1) / tiles;             // aim at >= target_blocks workgroups
-  const long long max_split = (P + 2047) / 2048;                        // at least 2048 pixels per slice
+  // at most target_blocks workgroups (two full rounds at four per compute unit: a few more would
+  // start a third, nearly empty round), at least 3584 pixels per slice (each slice ends in
+  // TM x TN float atomics)
+  long long splitk = target_blocks / tiles;
+  const long long max_split = (P + 3583) / 3584;
   if (splitk > max_split) splitk = max_split;
   if (splitk < 1) splitk = 1;
   // slices are rounded up to 64 pixels; drop the ones that rounding leaves empty
