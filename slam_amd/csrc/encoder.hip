@@ -357,6 +357,17 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
 #define SLAMHIP_PP_LOAD_B(dst, j)                                                                     \
   _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
     dst[kk] = *reinterpret_cast<const bf16x8*>(b_tile + b_off[j] + ((((kk * 2 + qh) ^ swz)) << 4));
+#define SLAMHIP_PP_MFMA2(ih)                                                                          \
+  __builtin_amdgcn_s_setprio(1);                                                                      \
+  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                   \
+      acc[(ih) * 2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq0[kk], acc[(ih) * 2 + i][0], 0, 0, 0); \
+      acc[(ih) * 2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq1[kk], acc[(ih) * 2 + i][1], 0, 0, 0); \
+    }                                                                                                 \
+  __builtin_amdgcn_s_setprio(0);                                                                      \
+  __builtin_amdgcn_sched_barrier(0);                                                                  \
+  __builtin_amdgcn_s_barrier();                                                                       \
+  __builtin_amdgcn_sched_barrier(0);
 #define SLAMHIP_PP_MFMA(ih, j, bsrc)                                                                  \
   __builtin_amdgcn_s_setprio(1);                                                                      \
   _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
@@ -381,29 +392,29 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
       const unsigned char* b_tile = a_tile + TILE_BYTES;
       const bool more = s + 1 < ksteps;
       const int nbuf = (s + 1) & 1;
+      // phase 1: rows 0-63 of the wave x all 64 columns (16 MFMAs); the whole next tile is requested here
       SLAMHIP_PP_LOAD_A(0);
       SLAMHIP_PP_LOAD_B(bq0, 0);
-      if (more) { SLAMHIP_IGEMM256_PART(nbuf, 0); SLAMHIP_IGEMM256_PART(nbuf, 1); }
-      SLAMHIP_PP_SECTION_END();
-      SLAMHIP_PP_MFMA(0, 0, bq0);
       SLAMHIP_PP_LOAD_B(bq1, 1);
-      if (more) SLAMHIP_IGEMM256_PART(nbuf, 2);
+      if (more) {
+        SLAMHIP_IGEMM256_PART(nbuf, 0); SLAMHIP_IGEMM256_PART(nbuf, 1);
+        SLAMHIP_IGEMM256_PART(nbuf, 2); SLAMHIP_IGEMM256_PART(nbuf, 3);
+        SLAMHIP_IGEMM256_ADVANCE();
+      }
       SLAMHIP_PP_SECTION_END();
-      SLAMHIP_PP_MFMA(0, 1, bq1);
+      SLAMHIP_PP_MFMA2(0);
+      // phase 2: rows 64-127 with the same B fragments
       SLAMHIP_PP_LOAD_A(1);
-      if (more) { SLAMHIP_IGEMM256_PART(nbuf, 3); SLAMHIP_IGEMM256_ADVANCE(); }
-      SLAMHIP_PP_SECTION_END();
-      SLAMHIP_PP_MFMA(1, 1, bq1);
-      SLAMHIP_PP_LOAD_B(bq0, 0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       SLAMHIP_PP_SECTION_END();
-      SLAMHIP_PP_MFMA(1, 0, bq0);
+      SLAMHIP_PP_MFMA2(1);
     }
     if (wm == 0) __builtin_amdgcn_s_barrier();
 #undef SLAMHIP_PP_SECTION_END
 #undef SLAMHIP_PP_LOAD_A
 #undef SLAMHIP_PP_LOAD_B
 #undef SLAMHIP_PP_MFMA
+#undef SLAMHIP_PP_MFMA2
   } else {
   SLAMHIP_IGEMM256_ISSUE(0);
   for (int s = 0; s < ksteps; ++s) {
@@ -1402,7 +1413,7 @@ static void launch_igemm256(const void* a, const void* b, void* out_bf16, long l
                             int flip, hipStream_t s, float* stat_part, int m_tile0 = 0, int m_tiles = -1) {
   if (m_tiles < 0) m_tiles = (int)((M + 255) / 256);
   const int n_tiles = N / 256, total = m_tiles * n_tiles;
-  static const bool pingpong = [] { const char* e = getenv("SLAMHIP_IGEMM256_PINGPONG"); return e ? atoi(e) != 0 : false; }();
+  static const bool pingpong = [] { const char* e = getenv("SLAMHIP_IGEMM256_PINGPONG"); return e ? atoi(e) != 0 : true; }();
   if (pingpong)
     hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS, true>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
                        (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
