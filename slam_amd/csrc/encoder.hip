@@ -239,19 +239,22 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
   // position lane & 7, fetching global chunk position ^ ((row >> 1) & 7)
   const bf16* a_src[4];
   const bf16* b_src[4];
-  int a_y[4], a_x[4];
-  bool a_row_ok[4];
+  unsigned int a_taps[4];   // bit t: the row exists and tap t of it lies inside the image
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int r = (wave * 4 + j) * 8 + (lane >> 3);
     const int g = (lane & 7) ^ ((r >> 1) & 7);
-    a_row_ok[j] = m0 + r < M;
-    const int pm = a_row_ok[j] ? m0 + r : M - 1;
-    a_y[j] = a_x[j] = 0;
+    const bool row_ok = m0 + r < M;
+    const int pm = row_ok ? m0 + r : M - 1;
+    a_taps[j] = row_ok ? 1u : 0u;
     if (TAPS == 9) {
       const int rem = pm % (H * W);
-      a_y[j] = rem / W;
-      a_x[j] = rem - a_y[j] * W;
+      const int y = rem / W, x = rem - y * W;
+      unsigned int mask = 0u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(y + t / 3 - 1) < (unsigned)H && (unsigned)(x + t % 3 - 1) < (unsigned)W) mask |= 1u << t;
+      a_taps[j] = row_ok ? mask : 0u;
     }
     a_src[j] = A + (long long)pm * C + g * 8;
     b_src[j] = Bw + (long long)(n0 + r) * Ktot + g * 8;
@@ -272,18 +275,16 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
   // request the tile (tap, c0) into buffer `buf` and advance the position
 #define SLAMHIP_IGEMM256_ISSUE(buf)                                                                  \
   {                                                                                                  \
-    int dy = 0, dx = 0;                                                                              \
+    int t = 0;                                                                                       \
+    long long delta = c0;                                                                            \
     if (TAPS == 9) {                                                                                 \
-      const int t = flip ? 8 - tap : tap;                                                            \
-      dy = t / 3 - 1;                                                                                \
-      dx = t - (t / 3) * 3 - 1;                                                                      \
+      t = flip ? 8 - tap : tap;                                                                      \
+      delta += (long long)((t / 3 - 1) * W + (t - (t / 3) * 3 - 1)) * C;                             \
     }                                                                                                \
     unsigned char* a_dst = lds + (buf) * 2 * TILE_BYTES + wave * 4096;                               \
     unsigned char* b_dst = a_dst + TILE_BYTES;                                                       \
     _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                  \
-      bool ok = a_row_ok[j];                                                                         \
-      if (TAPS == 9) ok = ok && (unsigned)(a_y[j] + dy) < (unsigned)H && (unsigned)(a_x[j] + dx) < (unsigned)W; \
-      const bf16* src = ok ? a_src[j] + (long long)(dy * W + dx) * C + c0 : zero_src;                \
+      const bf16* src = ((a_taps[j] >> t) & 1u) ? a_src[j] + delta : zero_src;                       \
       __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(a_dst + j * 1024), 16, 0, 0); \
     }                                                                                                \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                    \
@@ -308,16 +309,14 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
     unsigned char* a_dst = lds + (buf) * 2 * TILE_BYTES + wave * 4096;                               \
     unsigned char* b_dst = a_dst + TILE_BYTES;                                                       \
     if ((part) < 2) {                                                                                \
-      int dy = 0, dx = 0;                                                                            \
+      int t = 0;                                                                                     \
+      long long delta = c0;                                                                          \
       if (TAPS == 9) {                                                                               \
-        const int t = flip ? 8 - tap : tap;                                                          \
-        dy = t / 3 - 1;                                                                              \
-        dx = t - (t / 3) * 3 - 1;                                                                    \
+        t = flip ? 8 - tap : tap;                                                                    \
+        delta += (long long)((t / 3 - 1) * W + (t - (t / 3) * 3 - 1)) * C;                           \
       }                                                                                              \
       _Pragma("unroll") for (int j = 2 * (part); j < 2 * (part) + 2; ++j) {                          \
-        bool ok = a_row_ok[j];                                                                       \
-        if (TAPS == 9) ok = ok && (unsigned)(a_y[j] + dy) < (unsigned)H && (unsigned)(a_x[j] + dx) < (unsigned)W; \
-        const bf16* src = ok ? a_src[j] + (long long)(dy * W + dx) * C + c0 : zero_src;              \
+        const bf16* src = ((a_taps[j] >> t) & 1u) ? a_src[j] + delta : zero_src;                     \
         __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(a_dst + j * 1024), 16, 0, 0); \
       }                                                                                              \
     } else {                                                                                         \
