@@ -51,7 +51,7 @@ __device__ __forceinline__ uint4 and4(uint4 v, uint32_t keep) {
 // TAPS = 1: plain NT GEMM, A [M][C], Bw [N][C]
 // ---------------------------------------------------------------------------
 template <int TAPS, int BN, bool WRITE_BF16, bool WRITE_F32>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, BN == 128 ? 3 : 4)   // three 128-wide or four 64-wide workgroups per compute unit
 igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16,
                   float* __restrict__ out_f32, int M, int N, int C, int H, int W, int flip, int n_tiles,
                   int total_tiles, float* __restrict__ stat_part, int splitk, int m_tile0) {
