@@ -1393,8 +1393,11 @@ static unsigned int channel_stride_grid(long long total8, int C) {
 // rows are strided over the grid: enough blocks to fill the chip, at least ~8 rows per row lane
 static unsigned int reduce_grid(long long P, int C) {
   const int rlanes = 256 / (C / 8);
+  static const long long cap = [] { const char* e = getenv("SLAMHIP_REDUCE_BLOCKS"); return e ? atoll(e) : 1024LL; }();
+  // every block ends in 2C float atomics on the same addresses: beyond ~1024 blocks their
+  // serialisation costs more than the extra parallelism brings
   long long g = (P + 8LL * rlanes - 1) / (8LL * rlanes);
-  return (unsigned int)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+  return (unsigned int)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
 // 256 x 256 tiles: wide layers with enough pixel tiles to fill most of the chip
