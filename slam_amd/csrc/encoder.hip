@@ -333,13 +333,13 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
 
   if constexpr (PINGPONG) {
     // The two wave rows (wm = 0 / 1, one wave of each per SIMD) run half a phase apart: while one
-    // row's eight MFMAs of a quadrant occupy the matrix cores, the other row reads its next
-    // fragments from LDS and issues its share of the next tile's DMA loads.  Every section ends
-    // in a raw s_barrier, so the two rows alternate strictly; each wave executes the same
-    // number of barriers (the extra one in front for row 1, behind for row 0).
-    //   quadrants of a wave's 128 x 64 outputs per tile: (rows 0-63, cols 0-31), (0-63, 32-63),
-    //   (64-127, 32-63), (64-127, 0-31): each phase reloads only what changed.
-    // A load section waits for its own LDS reads (and, in the last phase of a tile, for its DMA
+    // row's sixteen MFMAs of a phase occupy the matrix cores, the other row reads its next
+    // fragments from LDS and, in the first phase of a tile, issues its share of the next tile's
+    // DMA loads.  Every section ends in a raw s_barrier, so the two rows alternate strictly; each
+    // wave executes the same number of barriers (the extra one in front for row 1, behind for
+    // row 0).  Two phases per tile: rows 0-63 of the wave's 128 x 64 outputs with all 64 columns
+    // (8 A and 8 B fragments), then rows 64-127 with the same B fragments (8 A fragments).
+    // A load section waits for its own LDS reads (and, in the second phase of a tile, for its DMA
     // loads of the next tile) BEFORE its barrier: a buffer is re-filled only after every read of
     // it has returned, and read only after every wave's loads into it have landed.
 #define SLAMHIP_PP_SECTION_END()                          \
@@ -363,15 +363,6 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
       acc[(ih) * 2 + i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq0[kk], acc[(ih) * 2 + i][0], 0, 0, 0); \
       acc[(ih) * 2 + i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bq1[kk], acc[(ih) * 2 + i][1], 0, 0, 0); \
     }                                                                                                 \
-  __builtin_amdgcn_s_setprio(0);                                                                      \
-  __builtin_amdgcn_sched_barrier(0);                                                                  \
-  __builtin_amdgcn_s_barrier();                                                                       \
-  __builtin_amdgcn_sched_barrier(0);
-#define SLAMHIP_PP_MFMA(ih, j, bsrc)                                                                  \
-  __builtin_amdgcn_s_setprio(1);                                                                      \
-  _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                    \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                     \
-      acc[(ih) * 2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][kk], bsrc[kk], acc[(ih) * 2 + i][j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0);                                                                      \
   __builtin_amdgcn_sched_barrier(0);                                                                  \
   __builtin_amdgcn_s_barrier();                                                                       \
@@ -412,7 +403,6 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
 #undef SLAMHIP_PP_SECTION_END
 #undef SLAMHIP_PP_LOAD_A
 #undef SLAMHIP_PP_LOAD_B
-#undef SLAMHIP_PP_MFMA
 #undef SLAMHIP_PP_MFMA2
   } else {
   SLAMHIP_IGEMM256_ISSUE(0);
