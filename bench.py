@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--size", default="480x640", help="frame size HxW (960x1280 = the high-resolution configuration)")
     ap.add_argument("--neighbours", type=int, default=1, help="neighbour frames warped per anchor (k)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline (0 = skip)")
-    ap.add_argument("--encoder-steps", type=int, default=3,
+    ap.add_argument("--encoder-steps", type=int, default=10,
                     help="training steps of the pose-regression encoder timed after the headline "
                          "measurement and reported under the 'encoder' key (0 = skip)")
     return ap.parse_args()
