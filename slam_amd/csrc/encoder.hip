@@ -614,6 +614,114 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
 }
 
 // ---------------------------------------------------------------------------
+// Filter gradient of the layers with wide images and few channels: the per-tap
+// kernel above reads X and dY nine times from L2 and is bound by that.  Here a workgroup owns
+// one filter ROW (dy fixed, dx = -1, 0, +1) of a 64 x 64 (ci x co) tile: a K-step is a segment
+// of 112 consecutive pixels of ONE image row, dY is staged once and X once with a one-pixel
+// halo on both sides (zeros outside the row, and the whole segment zero when row y + dy is
+// outside the image), and the three taps read the same X tile at row offsets 0, 1, 2.  No
+// per-tap masks, a third of the staging traffic, 21 MFMAs per wave and barrier pair.
+// W must be a multiple of 112.  Pixel slices are runs of segments; partial tiles are added to
+// the zeroed dW with float atomics.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+wgrad_rows64_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int B, int H,
+                    int W, int Cin, int Cout, int splitk, int total_work) {
+  constexpr int SEG = 112, PX = 64 + 32, PY = 64 + 32;
+  __shared__ __attribute__((aligned(16))) bf16 Xs[(SEG + 2) * PX];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[SEG * PY];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int per_xcd = (total_work + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_work) return;
+  const int ci_tiles = Cin / 64, co_tiles = Cout / 64, tiles = 3 * ci_tiles * co_tiles;
+  const int slice = work / tiles;
+  int rest = work - slice * tiles;
+  const int dyi = rest / (ci_tiles * co_tiles);            // filter row 0..2  (dy = dyi - 1)
+  rest -= dyi * ci_tiles * co_tiles;
+  const int ci0 = (rest / co_tiles) * 64, co0 = (rest % co_tiles) * 64;
+  const int spr = W / SEG;                                   // segments per image row
+  const int S = B * H * spr;
+  const int chunk = (S + splitk - 1) / splitk;
+  const int s_begin = slice * chunk, s_end = min(S, s_begin + chunk);
+  if (s_begin >= s_end) return;
+
+  // loader: two passes of 64 rows; thread -> row (tid >> 2) + 64 * pass, quarter tid & 3 of the
+  // 64 channels.  Rows that do not exist read pixel 0 and are zeroed by mask on the way into LDS.
+  const int l_row = tid >> 2, l_q = tid & 3;
+  const bf16* x_col = X + ci0 + l_q * 16;
+  const bf16* y_col = dY + co0 + l_q * 16;
+  f32x16 acc[3];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  uint4 rx[2][2], ry[2][2];
+  uint32_t keep_x[2] = {0u, 0u}, keep_y[2] = {0u, 0u};
+
+#define SLAMHIP_WROWS_ISSUE(seg)                                                                    \
+  {                                                                                                 \
+    const int R = (seg) / spr;                       /* global image row b * H + y */               \
+    const int x0 = ((seg) - R * spr) * SEG;                                                         \
+    const int b = R / H, ys = R - b * H + dyi - 1;                                                  \
+    const bool row_ok = (unsigned)ys < (unsigned)H;                                                 \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+      const int j = l_row + 64 * i;                    /* X tile row: pixel x0 - 1 + j */           \
+      const int x = x0 - 1 + j;                                                                     \
+      const bool okx = j < SEG + 2 && row_ok && (unsigned)x < (unsigned)W;                          \
+      const long long px = okx ? ((long long)(b * H + ys) * W + x) : 0;                             \
+      const uint4* xs = reinterpret_cast<const uint4*>(x_col + px * Cin);                           \
+      rx[i][0] = xs[0]; rx[i][1] = xs[1];                                                           \
+      keep_x[i] = okx ? 0xffffffffu : 0u;                                                           \
+      const bool oky = j < SEG;                         /* dY tile row: pixel x0 + j (< W) */       \
+      const long long py = oky ? ((long long)R * W + x0 + j) : 0;                                   \
+      const uint4* ysrc = reinterpret_cast<const uint4*>(y_col + py * Cout);                        \
+      ry[i][0] = ysrc[0]; ry[i][1] = ysrc[1];                                                       \
+      keep_y[i] = oky ? 0xffffffffu : 0u;                                                           \
+    }                                                                                               \
+  }
+
+  SLAMHIP_WROWS_ISSUE(s_begin);
+  for (int seg = s_begin; seg < s_end; ++seg) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int j = l_row + 64 * i;
+      if (j < SEG + 2) {
+        uint4* xd = reinterpret_cast<uint4*>(&Xs[j * PX + l_q * 16]);
+        xd[0] = and4(rx[i][0], keep_x[i]); xd[1] = and4(rx[i][1], keep_x[i]);
+      }
+      if (j < SEG) {
+        uint4* yd = reinterpret_cast<uint4*>(&Ys[j * PY + l_q * 16]);
+        yd[0] = and4(ry[i][0], keep_y[i]); yd[1] = and4(ry[i][1], keep_y[i]);
+      }
+    }
+    __syncthreads();
+    if (seg + 1 < s_end) SLAMHIP_WROWS_ISSUE(seg + 1);
+#pragma unroll
+    for (int kk = 0; kk < SEG; kk += 16) {
+      const bf16x8 bfr = tr_frag<PY>(Ys, kk, wn * 32, lane);              // B[k = pixel][n = co]
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {                                        // tap dx = t - 1: X pixel k + dx = tile row k + t
+        const bf16x8 af = tr_frag<PX>(Xs, kk + t, wm * 32, lane);         // A[m = ci][k = pixel]
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#undef SLAMHIP_WROWS_ISSUE
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      const int co = co0 + wn * 32 + (lane & 31);
+      atomicAdd(&dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co], acc[t][r]);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // first layer (Cin = 4, K = 36): too thin for the matrix cores, 0.8 % of the FLOPs
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1551,6 +1659,25 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   hipStream_t s = (hipStream_t)stream;
   const long long P = (long long)B * H * W;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "wgrad: too many pixels");
+  // up to 128 input channels on wide images: one workgroup per filter row and 64 x 64 tile (see the
+  // kernel; 1037 -> 726 us at 224 x 224 x 64 x 64, 772 -> 649 us at 112 x 112 x 128 x 128, batch 128).
+  // SLAMHIP_WGRAD_ROWS64 = 0 turns it off, n limits it to 64 n input channels.
+  static const int rows64 = [] { const char* e = getenv("SLAMHIP_WGRAD_ROWS64"); return e ? atoi(e) : 2; }();
+  if (rows64 && taps == 9 && Cin % 64 == 0 && Cin <= 64 * rows64 && W % 112 == 0 && P > 0) {
+    const long long tiles3 = 3LL * (Cin / 64) * (Cout / 64);
+    const long long S = (long long)B * H * (W / 112);
+    long long split = 1536 / tiles3;                  // two rounds at three workgroups per compute unit
+    if (split > S / 16) split = S / 16;               // at least 16 segments per slice
+    if (split < 1) split = 1;
+    const long long chunk = (S + split - 1) / split;
+    split = (S + chunk - 1) / chunk;
+    SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+    const long long total3 = tiles3 * split;
+    hipLaunchKernelGGL(wgrad_rows64_kernel, dim3((unsigned)((total3 + 7) / 8 * 8)), dim3(256), 0, s, (const bf16*)x,
+                       (const bf16*)dy, dw, B, H, W, Cin, Cout, (int)split, (int)total3);
+    SLAMHIP_HIP(hipGetLastError());
+    return SLAMHIP_OK;
+  }
   const int TM = Cin % 128 == 0 ? 128 : 64, TN = Cout % 128 == 0 ? 128 : 64;
   const long long tiles = (long long)(Cin / TM) * (Cout / TN) * taps;
   static const long long target_blocks = [] {

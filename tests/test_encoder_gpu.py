@@ -77,6 +77,21 @@ def test_wgrad_many_pixels_splitk(ops):
     close(dw, w.grad, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 5, 112, 64, 64), (1, 3, 224, 64, 128), (3, 1, 112, 64, 64),
+                                       (5, 40, 224, 64, 64), (2, 4, 112, 128, 128)])
+def test_wgrad_row_segment_kernel(ops, B, H, W, C, N):
+    """Up to 128 input channels on images whose width is a multiple of 112: the filter-row
+    kernel (segments of one image row with a one-pixel halo, three taps per workgroup),
+    including one-row images (the rows above and below do not exist) and many slices."""
+    x = rnd(B, H, W, C, seed=90).requires_grad_()
+    w = rnd(3, 3, C, N, seed=91, scale=0.05).requires_grad_()
+    dy = rnd(B, H, W, N, seed=92)
+    conv_ref(x, w).backward(dy)
+    dw = torch.full((3, 3, C, N), 7.0, dtype=torch.float32, device="cuda")
+    ops.wgrad(x.detach().cuda().to(BF), dy.cuda().to(BF), dw)
+    close(dw, w.grad, rtol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 6, 128), (130, 256, 192), (128, 64, 64), (1, 4096, 256)])
 def test_gemm_nt_and_fc_wgrad(ops, M, N, K):
     a, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.1)
