@@ -369,3 +369,32 @@ def test_fused_bn_relu_pool_matches_the_separate_kernels(B, H, W, C):
     np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-4, atol=1e-4)
     a, b = dz.float().cpu().numpy(), dz_ref.float().cpu().numpy()
     assert np.abs(a - b).max() <= 0.02 * np.abs(b).max() and (a != b).mean() < 0.02
+
+
+@pytest.mark.parametrize("B,H,W,C,N", [(3, 224, 224, 64, 64), (2, 260, 256, 128, 64), (11, 112, 112, 128, 64)])
+def test_filter_row_convolution_kernel(ops, B, H, W, C, N):
+    """Layers with many pixels (>= 128 Ki), at most 128 channels per tap and 64 outputs take the filter-row
+    kernel (one K-step per filter row, taps read the staged tile at row offsets, validity as
+    per-lane fragment masks): forward with fused statistics and data gradient against float32."""
+    x = rnd(B, H, W, C, seed=80, scale=0.5).requires_grad_()
+    w = rnd(3, 3, C, N, seed=81, scale=0.05).requires_grad_()
+    y = conv_ref(x, w)
+    dy = rnd(B, H, W, N, seed=82)
+    y.backward(dy)
+    xd, dyd = x.detach().cuda().to(BF), dy.cuda().to(BF)
+    w_fwd, w_dg = torch.empty(N, 9 * C, dtype=BF, device="cuda"), torch.empty(C, 9 * N, dtype=BF, device="cuda")
+    ops.conv_weight_layouts(w.detach().cuda(), w_fwd, w_dg)
+    out = torch.empty(B, H, W, N, dtype=BF, device="cuda")
+    sums = torch.empty(2, N, device="cuda")
+    ws = torch.empty(ops.conv_stats_workspace_bytes(B * H * W, N) // 4, device="cuda")
+    ops.conv3x3_stats(xd, w_fwd, out, sums, ws)
+    close(out, y)
+    z = out.float().reshape(-1, N).double()
+    close(sums[0], z.sum(0).float().cpu(), rtol=1e-5, atol=1e-2)
+    close(sums[1], (z * z).sum(0).float().cpu(), rtol=1e-5, atol=1e-2)
+    out2 = torch.empty_like(out)
+    ops.conv3x3(xd, w_fwd, out_bf16=out2)
+    assert torch.equal(out, out2)
+    dx = torch.empty(B, H, W, C, dtype=BF, device="cuda")
+    ops.conv3x3(dyd, w_dg, out_bf16=dx, flip=True)
+    close(dx, x.grad)
