@@ -937,13 +937,13 @@ __device__ __forceinline__ uint2 and2(uint2 v, uint32_t keep) { return make_uint
 // forward: 128 pixels x 64 filters per workgroup, one K-step
 __global__ void __launch_bounds__(256)
 conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, bf16* __restrict__ out, int P,
-                          int H, int W, float* __restrict__ stat_part) {
+                          int H, int W, float* __restrict__ stat_part, int tiles) {
   __shared__ __attribute__((aligned(16))) bf16 As[128 * LDS_PITCH];
   __shared__ __attribute__((aligned(16))) bf16 Bs[64 * LDS_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * 128;
-  // B[n][k] = filter[k][n] (k = tap * 4 + channel), zero for k >= 36
+  // B[n][k] = filter[k][n] (k = tap * 4 + channel), zero for k >= 36; once per workgroup, which
+  // then walks pixel tiles blockIdx.x, blockIdx.x + gridDim.x, ...
   {
     const int n = tid & 63, kg = tid >> 6;
 #pragma unroll
@@ -952,65 +952,85 @@ conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ 
       Bs[n * LDS_PITCH + k] = (bf16)(k < 36 ? Wt[k * 64 + n] : 0.0f);
     }
   }
-  // A[pixel][k]: thread -> pixel tid>>1; half 0 fills taps 0..4, half 1 taps 5..8 and the zero tail
-  {
-    const int row = tid >> 1, half = tid & 1;
-    const bool row_ok = m0 + row < P;
-    const int pm = row_ok ? m0 + row : P - 1;
-    const int rem = pm % (H * W), y = rem / W, x = rem - y * W;
-    const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
-    uint2* dst = reinterpret_cast<uint2*>(&As[row * LDS_PITCH]);
-    uint2 v[5];
-    uint32_t keep[5];
-#pragma unroll
-    for (int i = 0; i < 5; ++i) {
-      const int t = half * 5 + i;             // taps 0..4 | 5..9 (9 does not exist)
-      const int dy = t / 3 - 1, dx = t % 3 - 1;
-      const bool ok = row_ok && t < 9 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W;
-      v[i] = Xp[ok ? pm + dy * W + dx : pm];
-      keep[i] = ok ? 0xffffffffu : 0u;
-    }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) dst[half * 5 + i] = and2(v[i], keep[i]);   // k = 4 * tap ... (tap 9 = zeros)
-    if (half) {
-#pragma unroll
-      for (int i = 10; i < 16; ++i) dst[i] = make_uint2(0u, 0u);           // k = 40..63
-    }
+  // A[pixel][k]: thread -> pixel tid>>1; half 0 fills taps 0..4, half 1 taps 5..8 and the zero tail.
+  // The nine 8-byte pixels of the NEXT tile are fetched while the current one is computed and stored.
+  const int row = tid >> 1, half = tid & 1;
+  const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
+  uint2 v[5];
+  uint32_t keep[5];
+#define SLAMHIP_C4_FETCH(tile)                                                                              \
+  {                                                                                                         \
+    const int m0f = (tile) * 128;                                                                           \
+    const bool row_ok = m0f + row < P;                                                                      \
+    const int pm = row_ok ? m0f + row : P - 1;                                                              \
+    const int rem = pm % (H * W), y = rem / W, x = rem - y * W;                                             \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                         \
+      const int t = half * 5 + i;             /* taps 0..4 | 5..9 (9 does not exist) */                     \
+      const int dy = t / 3 - 1, dx = t % 3 - 1;                                                             \
+      const bool ok = row_ok && t < 9 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W; \
+      v[i] = Xp[ok ? pm + dy * W + dx : pm];                                                                \
+      keep[i] = ok ? 0xffffffffu : 0u;                                                                      \
+    }                                                                                                       \
   }
-  __syncthreads();
-  f32x16 acc[2];
+  int tile = blockIdx.x;
+  if (tile < tiles) SLAMHIP_C4_FETCH(tile);
+  for (; tile < tiles; tile += gridDim.x) {
+    const int m0 = tile * 128;
+    __syncthreads();          // the previous tile's staged output has been read (and Bs is written)
+    {
+      uint2* dst = reinterpret_cast<uint2*>(&As[row * LDS_PITCH]);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 5; ++i) dst[half * 5 + i] = and2(v[i], keep[i]);   // k = 4 * tap ... (tap 9 = zeros)
+      if (half) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
-#pragma unroll
-  for (int kk = 0; kk < 48; kk += 16) {   // k >= 48 is all zeros
-    const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
+        for (int i = 10; i < 16; ++i) dst[i] = make_uint2(0u, 0u);           // k = 40..63
+      }
     }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (m < P) out[(long long)m * 64 + wn * 32 + (lane & 31)] = (bf16)acc[i][r];
-    }
-  if (stat_part) {
-    float sm = 0.f, sq = 0.f;
+    __syncthreads();
+    if (tile + (int)gridDim.x < tiles) SLAMHIP_C4_FETCH(tile + (int)gridDim.x);
+    f32x16 acc[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = (float)(bf16)acc[i][r];
-        sm += v;
-        sq = __builtin_fmaf(v, v, sq);
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 48; kk += 16) {   // k >= 48 is all zeros
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&As[(wm * 64 + i * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[i], 0, 0, 0);
       }
-    store_column_stats(sm, sq, stat_part + ((long long)blockIdx.x * 2 + wm) * 128, wn * 32 + (lane & 31), 64, lane);
+    }
+    // the output tile goes through LDS (the im2col rows are no longer needed) so that it leaves
+    // in 16-byte stores of whole 128-byte pixel rows instead of 2-byte stores
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        As[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_PITCH + wn * 32 + (lane & 31)] = (bf16)acc[i][r];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int id = tid + 256 * k, orow = id >> 3, c8 = id & 7;
+      if (m0 + orow < P)
+        *reinterpret_cast<uint4*>(out + (long long)(m0 + orow) * 64 + c8 * 8) = *reinterpret_cast<const uint4*>(&As[orow * LDS_PITCH + c8 * 8]);
+    }
+    if (stat_part) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float vv = (float)(bf16)acc[i][r];
+          sm += vv;
+          sq = __builtin_fmaf(vv, vv, sq);
+        }
+      store_column_stats(sm, sq, stat_part + ((long long)tile * 2 + wm) * 128, wn * 32 + (lane & 31), 64, lane);
+    }
   }
+#undef SLAMHIP_C4_FETCH
 }
 
 // filter gradient: dW[k][n] += sum_p A[p][k] dY[p][n] over a slice of the pixels
@@ -1902,8 +1922,9 @@ static int small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, 
   const long long total = (long long)B * H * W * Cout;
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
-    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3((P + 127) / 128), dim3(256), 0, s, (const bf16*)x, w_hwio,
-                       (bf16*)out_bf16, P, H, W, stat_part);
+    const int tiles = (P + 127) / 128;
+    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, s, (const bf16*)x,
+                       w_hwio, (bf16*)out_bf16, P, H, W, stat_part, tiles);
   } else {
     hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16*)x, w_hwio,
                        (bf16*)out_bf16, P, H, W, Cin, Cout);
