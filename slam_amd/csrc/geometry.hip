@@ -546,26 +546,32 @@ __device__ __forceinline__ unsigned int blend_accumulate2(Acc& acc, const Cells&
 
 // Single-pixel form of blend_accumulate2 for the rare tiles that gather straight
 // from global memory; kept small so that it does not set the kernel's register count.
+// a_rg / a_b: the anchor's colour as biased binary16 patterns, half2(1024 + R, 1024 + G) and
+// half(1024 + B) in the low 16 bits.  m_ok: lane mask of warp_valid; returns the lane mask of
+// pixels that also have four non-zero depth taps.
 template <bool UNIT>
-__device__ __forceinline__ bool blend_accumulate1(Acc& acc, const Cells& t, float fu, float fv, bool ok, float factor_f,
-                                                  const unsigned int rgb[3], double d) {
+__device__ __forceinline__ unsigned long long blend_accumulate1(Acc& acc, const Cells& t, float fu, float fv,
+                                                                unsigned long long m_ok, float factor_f,
+                                                                unsigned int a_rg, unsigned int a_b, double d) {
   float top[4], bot[4], w[4];
   lerp_rows(t, fu, top, bot);
 #pragma unroll
   for (int c = 0; c < 4; ++c) w[c] = __builtin_fmaf(fv, bot[c] - top[c], top[c]);
-  // anchor colour with the cells' bias of 1024: half bits 0x6400 | byte
-  const float rr = w[0] - (float)__builtin_bit_cast(_Float16, (unsigned short)(0x6400u | rgb[0]));
-  const float rg = w[1] - (float)__builtin_bit_cast(_Float16, (unsigned short)(0x6400u | rgb[1]));
-  const float rb = w[2] - (float)__builtin_bit_cast(_Float16, (unsigned short)(0x6400u | rgb[2]));
-  const float okf = ok ? 1.0f : 0.0f;
+  // anchor - warped (the sign is irrelevant to |r| and r^2): one mixed-precision fma per channel,
+  // the anchor (same bias of 1024 as the cells) read as binary16 in place
+  float rr, rg, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rr) : "v"(w[0]), "v"(a_rg));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rg) : "v"(w[1]), "v"(a_rg));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(w[2]), "v"(a_b));
+  const float okf = __builtin_amdgcn_inverse_ballot_w64(m_ok) ? 1.0f : 0.0f;
   acc.ap.x = __builtin_fmaf(okf, (fabsf(rr) + fabsf(rg)) + fabsf(rb), acc.ap.x);
   acc.sp.x = __builtin_fmaf(okf, __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, rr * rr)), acc.sp.x);
   const float wd = UNIT ? w[3] : w[3] / factor_f;
-  const bool geo = ok && taps_nonzero(t);
-  const float g = geo ? (float)((double)wd - d) : 0.0f;
+  const unsigned long long m_geo = m_ok & __builtin_amdgcn_ballot_w64(taps_nonzero(t));
+  const float g = __builtin_amdgcn_inverse_ballot_w64(m_geo) ? (float)((double)wd - d) : 0.0f;
   acc.ag.x += fabsf(g);
   acc.sg.x = __builtin_fmaf(g, g, acc.sg.x);
-  return geo;
+  return m_geo;
 }
 
 __device__ __forceinline__ uint2 global_cell(const uint16_t* __restrict__ d2, const uint8_t* __restrict__ c2, int W,
@@ -587,11 +593,17 @@ __device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u
   v = y2 * (float)c.fy * rz + (float)c.cy;
 }
 
+// W, H, W - 1, H - 1 as float64: kernel arguments stay in scalar registers, where the
+// compares read them (converted in the kernel they are rebuilt by vector instructions per pixel)
+struct Bounds {
+  double w, h, w1, h1;
+};
+
 template <bool FAST, bool UNIT>
 __global__ void __launch_bounds__(TPB, SLAMHIP_FUSED_WAVES)
 pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
                        const uint16_t* __restrict__ depth2, const uint8_t* __restrict__ rgb2,
-                       const double* __restrict__ rel, Cam cam, int B, int k, int H, int W,
+                       const double* __restrict__ rel, Cam cam, Bounds bnd, int B, int k, int H, int W,
                        int tiles_x, int tiles_y, int stage_vec, PairAcc* __restrict__ ws,
                        double* __restrict__ sums, unsigned int* __restrict__ counts) {
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
@@ -610,13 +622,14 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
   const int tx = tile % tiles_x, ty = tile / tiles_x;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // known to be wave-uniform
   const long long HW = (long long)H * W;
   // step i of a thread = row (i>>1) of its wave's four rows, column (i&1)*64 + lane
   const int row0 = ty * TILE_H + wave * (STEPS / 2);
   const int colA = tx * TILE_W + lane;
   unsigned int live = (1u << STEPS) - 1u;
-  if ((tx + 1) * TILE_W > W || (ty + 1) * TILE_H > H) {   // edge tile: some steps fall outside the image
+  const bool edge = (tx + 1) * TILE_W > W || (ty + 1) * TILE_H > H;   // wave-uniform
+  if (edge) {   // some steps fall outside the image
     live = 0;
 #pragma unroll
     for (int i = 0; i < STEPS; ++i) {
@@ -629,15 +642,23 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
   const uint8_t* c1p = rgb1 + 3 * (long long)b * HW;
   // a step outside the image is masked by `live`; clamping the offset keeps its loads in bounds
   const int aoff0 = row0 * W + colA, alast = H * W - 1;
-  auto anchor_offset = [&](int i) { return min(aoff0 + (i >> 1) * W + (i & 1) * 64, alast); };
+  auto anchor_offset = [&](int i) { return (unsigned int)min(aoff0 + (i >> 1) * W + (i & 1) * 64, alast); };
 
-  const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
+  const double dW = bnd.w, dH = bnd.h, dW1 = bnd.w1, dH1 = bnd.h1;
   const float factor_f = (float)cam.factor;
   // divisor-only parts of the three constant divisions (UNIT: factor == 1, z is the raw depth)
   const double r_fx = FAST ? refined_rcp(cam.fx) : 0.0;
   const double r_fy = FAST ? refined_rcp(cam.fy) : 0.0;
   const double r_fac = (FAST && !UNIT) ? refined_rcp(cam.factor) : 0.0;
   const double ucx0 = (double)colA - cam.cx, ucx1 = (double)(colA + 64) - cam.cx;
+  // lane masks of "u - cx != 0" for the two columns and a bit per row of "v - cy != 0" (wave-uniform)
+  // and of the step lying inside the image (column per lane, row per wave)
+  const unsigned long long col_nz0 = __builtin_amdgcn_ballot_w64(ucx0 != 0.0 && colA < W);
+  const unsigned long long col_nz1 = __builtin_amdgcn_ballot_w64(ucx1 != 0.0 && colA + 64 < W);
+  unsigned int rows_nz = 0u;
+#pragma unroll
+  for (int r = 0; r < STEPS / 2; ++r)
+    rows_nz |= (__builtin_amdgcn_ballot_w64((double)(row0 + r) - cam.cy != 0.0) != 0ull && row0 + r < H) ? (1u << r) : 0u;
 
   // range of non-zero anchor depth in the tile: found on first need (see below)
   unsigned int zmn = 0xffffu, zmx = 0u;
@@ -686,7 +707,7 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
       float pu, pv, pz;
       project_f32(cam, p, (float)cx_, (float)cy_, zc, pu, pv, pz);
       const bool okp = (lane < 8) && (pz > 0.0f) && (fabsf(pu) < 1e6f) && (fabsf(pv) < 1e6f);   // NaN fails
-      const bool bad = __ballot((lane < 8) && !okp) != 0ull;
+      const bool bad = __builtin_amdgcn_ballot_w64((lane < 8) && !okp) != 0ull;
       const int lo_u = okp ? max((int)floorf(pu) - 2, 0) : 0x7fff, lo_v = okp ? max((int)floorf(pv) - 2, 0) : 0x7fff;
       const int hi_u = okp ? min((int)floorf(pu) + 3, W - 1) : 0, hi_v = okp ? min((int)floorf(pv) + 3, H - 1) : 0;
       const unsigned int pmin = oct_pk_min(((unsigned int)min(lo_v, 0x7fff) << 16) | (unsigned int)min(lo_u, 0xffff));
@@ -747,24 +768,28 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
     const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
     // anchor depth and colour are (re)loaded one step ahead of their use; the
     // loop is deliberately not unrolled: one pixel's live set, small code
-    unsigned int nxt[4];
+    unsigned int nxt[3];   // R | G << 8, B, raw depth
     {
-      const int o = anchor_offset(0);
-      nxt[0] = c1p[3 * o]; nxt[1] = c1p[3 * o + 1]; nxt[2] = c1p[3 * o + 2]; nxt[3] = d1b[o];
+      const unsigned int o = anchor_offset(0);
+      const uint8_t* cp = c1p + 3u * o;
+      nxt[0] = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8); nxt[1] = cp[2]; nxt[2] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(d1b) + 2u * o);
     }
 #ifndef SLAMHIP_ABL_NO_GATHER
 #pragma unroll 1
     for (int i = 0; i < STEPS; ++i) {
-      const unsigned int rgb[3] = {nxt[0], nxt[1], nxt[2]};
-      const unsigned int draw_i = ((live >> i) & 1u) ? nxt[3] : 0u;
+      // bytes {R, 0x64, G, 0x64} = half2(1024 + R, 1024 + G); 0x6400 | B = half(1024 + B)
+      const unsigned int a_rg = __builtin_amdgcn_perm(0x64u, nxt[0], 0x04010400u), a_b = 0x6400u | nxt[1];
+      const unsigned int draw_i = nxt[2];   // a step outside the image has no bit in the valid0 masks
       {
-        const int o = anchor_offset(min(i + 1, STEPS - 1));
-        nxt[0] = c1p[3 * o]; nxt[1] = c1p[3 * o + 1]; nxt[2] = c1p[3 * o + 2]; nxt[3] = d1b[o];
+        const unsigned int o = anchor_offset(min(i + 1, STEPS - 1));
+        const uint8_t* cp = c1p + 3u * o;
+        nxt[0] = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8); nxt[1] = cp[2]; nxt[2] = *reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(d1b) + 2u * o);
       }
       const double ucx = (i & 1) ? ucx1 : ucx0;
       const double vcy = (double)(row0 + (i >> 1)) - cam.cy;
       double x, y, z, x2, y2, z2, u, v;
-      bool valid0;
+      // Predicates live as 64-bit lane masks (one compare each, combined on the scalar unit)
+      unsigned long long m_valid0;
       if (FAST) {
         // test_import.py:153-155 with the constant divisors' reciprocals hoisted
         z = UNIT ? (double)draw_i : div_by((double)draw_i, cam.factor, r_fac);
@@ -772,12 +797,14 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
         y = div_by(vcy * z, cam.fy, r_fy);
         // no product above can underflow (the host checked the constants), so
         // "x, y, z all non-zero" is "raw depth, u-cx and v-cy all non-zero"
-        valid0 = (draw_i != 0u) && (ucx != 0.0) && (vcy != 0.0);
+        m_valid0 = __builtin_amdgcn_ballot_w64(draw_i != 0u) & ((i & 1) ? col_nz1 : col_nz0);
+        if (!((rows_nz >> (i >> 1)) & 1u)) m_valid0 = 0ull;
       } else {
         z = UNIT ? (double)draw_i : (double)draw_i / cam.factor;
         x = (ucx * z) / cam.fx;
         y = (vcy * z) / cam.fy;
-        valid0 = (x != 0.0) && (y != 0.0) && (z != 0.0) && ((live >> i) & 1u);
+        m_valid0 = __builtin_amdgcn_ballot_w64(x != 0.0) & __builtin_amdgcn_ballot_w64(y != 0.0) &
+                   __builtin_amdgcn_ballot_w64(z != 0.0) & __builtin_amdgcn_ballot_w64(((live >> i) & 1u) != 0u);
       }
       transform_px(p, x, y, z, x2, y2, z2);
       const double nu = x2 * cam.fx, nv = y2 * cam.fy;
@@ -786,43 +813,51 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
         // tiny, huge or non-finite numerator gives a quotient that is either exact
         // or (tiny) absorbed by "+ cx" / (huge, NaN) outside every window either
         // way, because the host admitted only |cx|, |cy| in [2^-32, 2^32].
-        const bool band = in_band(z2);
+        const unsigned long long m_band = __builtin_amdgcn_ballot_w64(in_band(z2));
         const double r_z = refined_rcp(z2);
         u = div_by(nu, z2, r_z) + cam.cx;
         v = div_by(nv, z2, r_z) + cam.cy;
-        if (valid0 && !band) {   // zero / huge / tiny / non-finite divisor: plain IEEE division
-          u = nu / z2 + cam.cx;
-          v = nv / z2 + cam.cy;
+        const unsigned long long m_plain = m_valid0 & ~m_band;
+        if (m_plain != 0ull) {   // zero / huge / tiny / non-finite divisor: plain IEEE division
+          if (__builtin_amdgcn_inverse_ballot_w64(m_plain)) {
+            u = nu / z2 + cam.cx;
+            v = nv / z2 + cam.cy;
+          }
         }
       } else {
         u = nu / z2 + cam.cx;
         v = nv / z2 + cam.cy;
       }
-      const bool inb = valid0 & in_window(u, v, dW, dH);
-      const bool wv = valid0 & in_window(u, v, dW1, dH1) & (z2 > 0.0);
-      n_valid0 += (unsigned int)__popcll(__ballot(valid0));
-      n_inb += (unsigned int)__popcll(__ballot(inb));
-      n_warp += (unsigned int)__popcll(__ballot(wv));
+      // test_import.py:174 (inclusive on both ends, NaN fails) and the tap window one pixel inside it
+      const unsigned long long m_ge0 = m_valid0 & __builtin_amdgcn_ballot_w64(0.0 <= u) & __builtin_amdgcn_ballot_w64(0.0 <= v);
+      const unsigned long long m_inb = m_ge0 & __builtin_amdgcn_ballot_w64(u <= dW) & __builtin_amdgcn_ballot_w64(v <= dH);
+      const unsigned long long m_wv = m_ge0 & __builtin_amdgcn_ballot_w64(u <= dW1) & __builtin_amdgcn_ballot_w64(v <= dH1) &
+                                      __builtin_amdgcn_ballot_w64(z2 > 0.0);
+      n_valid0 += (unsigned int)__popcll(m_valid0);
+      n_inb += (unsigned int)__popcll(m_inb);
+      n_warp += (unsigned int)__popcll(m_wv);
+      const bool wv = __builtin_amdgcn_inverse_ballot_w64(m_wv);
       // u, v >= 0 when warp_valid: truncation is floor and fract() is u - floor(u);
       // the weights of pixels that do not warp are zeroed (their u, v may be NaN/inf)
       const int iu = wv ? (int)u : 0, iv = wv ? (int)v : 0;
       const float fu = wv ? (float)__builtin_amdgcn_fract(u) : 0.0f;
       const float fv = wv ? (float)__builtin_amdgcn_fract(v) : 0.0f;
       const int du = iu - wx0, dv_ = iv - wy0;
-      const bool hit = wv && ((unsigned int)du < lim_u) && ((unsigned int)dv_ < lim_v);
+      const unsigned long long m_hit = m_wv & __builtin_amdgcn_ballot_w64((unsigned int)du < lim_u) &
+                                       __builtin_amdgcn_ballot_w64((unsigned int)dv_ < lim_v);
+      const bool hit = __builtin_amdgcn_inverse_ballot_w64(m_hit);
       const uint2* cell = win + (hit ? dv_ * WIN_PITCH + du : 0);
       Cells t;
       t.a = cell[0]; t.b = cell[1]; t.c = cell[WIN_PITCH]; t.e = cell[WIN_PITCH + 1];
-      const bool miss = wv && !hit;
-      if (__ballot(miss) != 0ull) {   // rare: taps outside the staged window
-        if (miss) {
+      const unsigned long long m_miss = m_wv & ~m_hit;
+      if (m_miss != 0ull) {   // rare: taps outside the staged window
+        if (__builtin_amdgcn_inverse_ballot_w64(m_miss)) {
           const int x1 = min(iu + 1, W - 1), y1 = min(iv + 1, H - 1);
           t.a = global_cell(d2, c2, W, iu, iv); t.b = global_cell(d2, c2, W, x1, iv);
           t.c = global_cell(d2, c2, W, iu, y1); t.e = global_cell(d2, c2, W, x1, y1);
         }
       }
-      const bool geo = blend_accumulate1<UNIT>(acc, t, fu, fv, wv, factor_f, rgb, z2);
-      n_geo += (unsigned int)__popcll(__ballot(geo));
+      n_geo += (unsigned int)__popcll(blend_accumulate1<UNIT>(acc, t, fu, fv, m_wv, factor_f, a_rg, a_b, z2));
     }
 #endif
 
@@ -969,6 +1004,7 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
   const long long nblocks = groups * 8 * tiles_x * tiles_y;
   SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "pair_loss_fused: grid too large");
   const Cam cam{K[0], K[1], K[2], K[3], factor};
+  const Bounds bnd{(double)W, (double)H, (double)(W - 1), (double)(H - 1)};
   // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
   const int stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
   // hoisted-reciprocal divisions are exact while nothing comes near the denormal
@@ -980,7 +1016,7 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
   const bool unit = factor == 1.0;
 #define SLAMHIP_LAUNCH_FUSED(F, U)                                                                         \
   hipLaunchKernelGGL((pair_loss_fused_kernel<F, U>), dim3((unsigned)nblocks), dim3(TPB), 0, s, depth1, rgb1, \
-                     depth2, rgb2, rel4x4, cam, B, k, H, W, tiles_x, tiles_y, stage_vec, ws, sums, counts)
+                     depth2, rgb2, rel4x4, cam, bnd, B, k, H, W, tiles_x, tiles_y, stage_vec, ws, sums, counts)
   if (fast && unit) SLAMHIP_LAUNCH_FUSED(true, true);
   else if (fast) SLAMHIP_LAUNCH_FUSED(true, false);
   else if (unit) SLAMHIP_LAUNCH_FUSED(false, true);
