@@ -593,17 +593,11 @@ __device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u
   v = y2 * (float)c.fy * rz + (float)c.cy;
 }
 
-// W, H, W - 1, H - 1 as float64: kernel arguments stay in scalar registers, where the
-// compares read them (converted in the kernel they are rebuilt by vector instructions per pixel)
-struct Bounds {
-  double w, h, w1, h1;
-};
-
 template <bool FAST, bool UNIT>
 __global__ void __launch_bounds__(TPB, SLAMHIP_FUSED_WAVES)
 pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
                        const uint16_t* __restrict__ depth2, const uint8_t* __restrict__ rgb2,
-                       const double* __restrict__ rel, Cam cam, Bounds bnd, int B, int k, int H, int W,
+                       const double* __restrict__ rel, Cam cam, int B, int k, int H, int W,
                        int tiles_x, int tiles_y, int stage_vec, PairAcc* __restrict__ ws,
                        double* __restrict__ sums, unsigned int* __restrict__ counts) {
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
@@ -627,38 +621,28 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
   // step i of a thread = row (i>>1) of its wave's four rows, column (i&1)*64 + lane
   const int row0 = ty * TILE_H + wave * (STEPS / 2);
   const int colA = tx * TILE_W + lane;
-  unsigned int live = (1u << STEPS) - 1u;
-  const bool edge = (tx + 1) * TILE_W > W || (ty + 1) * TILE_H > H;   // wave-uniform
-  if (edge) {   // some steps fall outside the image
-    live = 0;
-#pragma unroll
-    for (int i = 0; i < STEPS; ++i) {
-      const int r = row0 + (i >> 1), c = colA + (i & 1) * 64;
-      live |= ((r < H) && (c < W)) ? (1u << i) : 0u;
-    }
-  }
   // wave-uniform plane bases + 32-bit per-lane offsets (clamped into the image)
   const uint16_t* d1b = depth1 + (long long)b * HW;
   const uint8_t* c1p = rgb1 + 3 * (long long)b * HW;
-  // a step outside the image is masked by `live`; clamping the offset keeps its loads in bounds
+  // a step outside the image has no bit in the masks below; clamping the offset keeps its loads in bounds
   const int aoff0 = row0 * W + colA, alast = H * W - 1;
   auto anchor_offset = [&](int i) { return (unsigned int)min(aoff0 + (i >> 1) * W + (i & 1) * 64, alast); };
 
-  const double dW = bnd.w, dH = bnd.h, dW1 = bnd.w1, dH1 = bnd.h1;
+  const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
   const float factor_f = (float)cam.factor;
   // divisor-only parts of the three constant divisions (UNIT: factor == 1, z is the raw depth)
   const double r_fx = FAST ? refined_rcp(cam.fx) : 0.0;
   const double r_fy = FAST ? refined_rcp(cam.fy) : 0.0;
   const double r_fac = (FAST && !UNIT) ? refined_rcp(cam.factor) : 0.0;
   const double ucx0 = (double)colA - cam.cx, ucx1 = (double)(colA + 64) - cam.cx;
-  // lane masks of "u - cx != 0" for the two columns and a bit per row of "v - cy != 0" (wave-uniform)
-  // and of the step lying inside the image (column per lane, row per wave)
-  const unsigned long long col_nz0 = __builtin_amdgcn_ballot_w64(ucx0 != 0.0 && colA < W);
-  const unsigned long long col_nz1 = __builtin_amdgcn_ballot_w64(ucx1 != 0.0 && colA + 64 < W);
+  // Lane masks of the step lying inside the image for the two columns, and a bit per row (wave-
+  // uniform); FAST: and of "u - cx != 0" / "v - cy != 0", the per-column and per-row parts of valid0
+  const unsigned long long col_nz0 = __builtin_amdgcn_ballot_w64((!FAST || ucx0 != 0.0) && colA < W);
+  const unsigned long long col_nz1 = __builtin_amdgcn_ballot_w64((!FAST || ucx1 != 0.0) && colA + 64 < W);
   unsigned int rows_nz = 0u;
 #pragma unroll
   for (int r = 0; r < STEPS / 2; ++r)
-    rows_nz |= (__builtin_amdgcn_ballot_w64((double)(row0 + r) - cam.cy != 0.0) != 0ull && row0 + r < H) ? (1u << r) : 0u;
+    rows_nz |= ((!FAST || __builtin_amdgcn_ballot_w64((double)(row0 + r) - cam.cy != 0.0) != 0ull) && row0 + r < H) ? (1u << r) : 0u;
 
   // range of non-zero anchor depth in the tile: found on first need (see below)
   unsigned int zmn = 0xffffu, zmx = 0u;
@@ -682,13 +666,14 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
                            (fabsf((float)p.t0) + fabsf((float)p.t1) + fabsf((float)p.t2));
     const bool depth_free = shift_px < 0.5f;   // NaN: false
     if (!depth_free && !have_range) {
-      unsigned int draw[STEPS];
-#pragma unroll
-      for (int i = 0; i < STEPS; ++i) draw[i] = ((live >> i) & 1u) ? (unsigned int)d1b[anchor_offset(i)] : 0u;
-#pragma unroll
+      // rolled on purpose: unrolled, its address arithmetic is hoisted out of the neighbour loop
+      // and holds registers through the whole kernel for a branch that is rarely taken
+#pragma unroll 1
       for (int i = 0; i < STEPS; ++i) {
-        zmn = min(zmn, draw[i] ? draw[i] : 0xffffu);
-        zmx = max(zmx, draw[i]);
+        const bool inside = (row0 + (i >> 1) < H) && (colA + (i & 1) * 64 < W);
+        const unsigned int dr = inside ? (unsigned int)d1b[anchor_offset(i)] : 0u;
+        zmn = min(zmn, dr ? dr : 0xffffu);
+        zmx = max(zmx, dr);
       }
       const unsigned int pk = wave_pk_min63(zmn | 0xffff0000u), px = wave_pk_max63(zmx);
       if (lane == 63) { s_rng[wave][0] = pk; s_rng[wave][1] = px; }
@@ -798,14 +783,14 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
         // no product above can underflow (the host checked the constants), so
         // "x, y, z all non-zero" is "raw depth, u-cx and v-cy all non-zero"
         m_valid0 = __builtin_amdgcn_ballot_w64(draw_i != 0u) & ((i & 1) ? col_nz1 : col_nz0);
-        if (!((rows_nz >> (i >> 1)) & 1u)) m_valid0 = 0ull;
       } else {
         z = UNIT ? (double)draw_i : (double)draw_i / cam.factor;
         x = (ucx * z) / cam.fx;
         y = (vcy * z) / cam.fy;
         m_valid0 = __builtin_amdgcn_ballot_w64(x != 0.0) & __builtin_amdgcn_ballot_w64(y != 0.0) &
-                   __builtin_amdgcn_ballot_w64(z != 0.0) & __builtin_amdgcn_ballot_w64(((live >> i) & 1u) != 0u);
+                   __builtin_amdgcn_ballot_w64(z != 0.0) & ((i & 1) ? col_nz1 : col_nz0);
       }
+      if (!((rows_nz >> (i >> 1)) & 1u)) m_valid0 = 0ull;
       transform_px(p, x, y, z, x2, y2, z2);
       const double nu = x2 * cam.fx, nv = y2 * cam.fy;
       if (FAST) {
@@ -1004,7 +989,6 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
   const long long nblocks = groups * 8 * tiles_x * tiles_y;
   SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "pair_loss_fused: grid too large");
   const Cam cam{K[0], K[1], K[2], K[3], factor};
-  const Bounds bnd{(double)W, (double)H, (double)(W - 1), (double)(H - 1)};
   // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
   const int stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
   // hoisted-reciprocal divisions are exact while nothing comes near the denormal
@@ -1016,7 +1000,7 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
   const bool unit = factor == 1.0;
 #define SLAMHIP_LAUNCH_FUSED(F, U)                                                                         \
   hipLaunchKernelGGL((pair_loss_fused_kernel<F, U>), dim3((unsigned)nblocks), dim3(TPB), 0, s, depth1, rgb1, \
-                     depth2, rgb2, rel4x4, cam, bnd, B, k, H, W, tiles_x, tiles_y, stage_vec, ws, sums, counts)
+                     depth2, rgb2, rel4x4, cam, B, k, H, W, tiles_x, tiles_y, stage_vec, ws, sums, counts)
   if (fast && unit) SLAMHIP_LAUNCH_FUSED(true, true);
   else if (fast) SLAMHIP_LAUNCH_FUSED(true, false);
   else if (unit) SLAMHIP_LAUNCH_FUSED(false, true);
