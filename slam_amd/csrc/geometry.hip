@@ -494,9 +494,11 @@ __device__ __forceinline__ void lerp_rows(const Cells& t, float fu, float top[4]
   bot[0] = __builtin_fmaf(fu, (float)dB.x, (float)cRG.x);
   bot[1] = __builtin_fmaf(fu, (float)dB.y, (float)cRG.y);
   bot[2] = __builtin_fmaf(fu, (float)dBb, (float)cB);
-  const float da = (float)(t.a.y >> 16), db = (float)(t.b.y >> 16), dc = (float)(t.c.y >> 16), de = (float)(t.e.y >> 16);
-  top[3] = __builtin_fmaf(fu, db - da, da);
-  bot[3] = __builtin_fmaf(fu, de - dc, dc);
+  // depth, top and bottom row at once (packed float32: both lanes of an instruction are used)
+  const float2_t d_ac = {(float)(t.a.y >> 16), (float)(t.c.y >> 16)}, d_be = {(float)(t.b.y >> 16), (float)(t.e.y >> 16)};
+  const float2_t d_tb = __builtin_elementwise_fma(float2_t{fu, fu}, d_be - d_ac, d_ac);
+  top[3] = d_tb.x;
+  bot[3] = d_tb.y;
 }
 
 __device__ __forceinline__ bool taps_nonzero(const Cells& t) {  // all four raw depths != 0
@@ -555,8 +557,14 @@ __device__ __forceinline__ unsigned long long blend_accumulate1(Acc& acc, const 
                                                                 unsigned int a_rg, unsigned int a_b, double d) {
   float top[4], bot[4], w[4];
   lerp_rows(t, fu, top, bot);
-#pragma unroll
-  for (int c = 0; c < 4; ++c) w[c] = __builtin_fmaf(fv, bot[c] - top[c], top[c]);
+  {   // vertical step: red and green in one packed instruction
+    const float2_t t01 = {top[0], top[1]}, b01 = {bot[0], bot[1]};
+    const float2_t w01 = __builtin_elementwise_fma(float2_t{fv, fv}, b01 - t01, t01);
+    w[0] = w01.x;
+    w[1] = w01.y;
+    w[2] = __builtin_fmaf(fv, bot[2] - top[2], top[2]);
+    w[3] = __builtin_fmaf(fv, bot[3] - top[3], top[3]);
+  }
   // anchor - warped (the sign is irrelevant to |r| and r^2): one mixed-precision fma per channel,
   // the anchor (same bias of 1024 as the cells) read as binary16 in place
   float rr, rg, rb;
@@ -564,8 +572,10 @@ __device__ __forceinline__ unsigned long long blend_accumulate1(Acc& acc, const 
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rg) : "v"(w[1]), "v"(a_rg));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(w[2]), "v"(a_b));
   const float okf = __builtin_amdgcn_inverse_ballot_w64(m_ok) ? 1.0f : 0.0f;
-  acc.ap.x = __builtin_fmaf(okf, (fabsf(rr) + fabsf(rg)) + fabsf(rb), acc.ap.x);
-  acc.sp.x = __builtin_fmaf(okf, __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, rr * rr)), acc.sp.x);
+  const float2_t as = {(fabsf(rr) + fabsf(rg)) + fabsf(rb), __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, rr * rr))};
+  const float2_t acc_as = __builtin_elementwise_fma(float2_t{okf, okf}, as, float2_t{acc.ap.x, acc.sp.x});
+  acc.ap.x = acc_as.x;
+  acc.sp.x = acc_as.y;
   const float wd = UNIT ? w[3] : w[3] / factor_f;
   const unsigned long long m_geo = m_ok & __builtin_amdgcn_ballot_w64(taps_nonzero(t));
   const float g = __builtin_amdgcn_inverse_ballot_w64(m_geo) ? (float)((double)wd - d) : 0.0f;
@@ -823,15 +833,19 @@ pair_loss_fused_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __res
       n_warp += (unsigned int)__popcll(m_wv);
       const bool wv = __builtin_amdgcn_inverse_ballot_w64(m_wv);
       // u, v >= 0 when warp_valid: truncation is floor and fract() is u - floor(u);
+      // (the conversion instruction saturates and maps NaN to 0, so it runs on every lane;
+      // only lanes of m_wv, where 0 <= u <= W - 1 and 0 <= v <= H - 1, use the index);
       // the weights of pixels that do not warp are zeroed (their u, v may be NaN/inf)
-      const int iu = wv ? (int)u : 0, iv = wv ? (int)v : 0;
+      int iu, iv;
+      asm("v_cvt_i32_f64 %0, %1" : "=v"(iu) : "v"(u));
+      asm("v_cvt_i32_f64 %0, %1" : "=v"(iv) : "v"(v));
       const float fu = wv ? (float)__builtin_amdgcn_fract(u) : 0.0f;
       const float fv = wv ? (float)__builtin_amdgcn_fract(v) : 0.0f;
-      const int du = iu - wx0, dv_ = iv - wy0;
+      const int du = (int)((unsigned int)iu - (unsigned int)wx0), dv_ = (int)((unsigned int)iv - (unsigned int)wy0);   // may wrap in lanes outside m_wv
       const unsigned long long m_hit = m_wv & __builtin_amdgcn_ballot_w64((unsigned int)du < lim_u) &
                                        __builtin_amdgcn_ballot_w64((unsigned int)dv_ < lim_v);
       const bool hit = __builtin_amdgcn_inverse_ballot_w64(m_hit);
-      const uint2* cell = win + (hit ? dv_ * WIN_PITCH + du : 0);
+      const uint2* cell = win + (hit ? (unsigned int)dv_ * WIN_PITCH + (unsigned int)du : 0u);
       Cells t;
       t.a = cell[0]; t.b = cell[1]; t.c = cell[WIN_PITCH]; t.e = cell[WIN_PITCH + 1];
       const unsigned long long m_miss = m_wv & ~m_hit;
