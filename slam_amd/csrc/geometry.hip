@@ -307,19 +307,21 @@ warp_materialize_kernel(const uint16_t* __restrict__ depth1, const uint8_t* __re
 // pixels, so that at every step the 64 lanes of a wave read 64 adjacent anchor
 // pixels (coalesced) and gather from adjacent LDS cells (no bank conflicts for
 // the smooth flow of small camera motions).  Per neighbour frame:
-//   A  project the eight pixels (float64), keep (tap address, fu, fv, d, flags);
-//   B  workgroup bounding box of the bilinear taps (DPP min/max, then LDS);
-//   C  stage that window of the neighbour frame into LDS as 8-byte cells
-//      {R|G<<8|B<<16, float(depth)} with 16-byte / 8-byte global loads;
-//   D  gather the four taps of every pixel from LDS, blend, accumulate;
-//   a window wider than WIN_PITCH or taller than WIN_ROWS (large parallax)
-//   falls back to gathering straight from global memory for that tile.
-// Reduction: counts by ballot+popcount, sums by DPP row reductions, the four
-// waves through LDS, then one float64 / uint32 atomic per quantity per
-// workgroup into the accumulators of the caller's workspace.  The workgroup
-// that draws the last ticket of an (image, neighbour) pair moves the totals to
-// the outputs with atomic exchanges, which also leaves the workspace zeroed for
-// the next call: no memset and no second kernel on the stream.
+//   A  predict the window of the neighbour frame the tile's taps fall into (the
+//      tile's corners projected in float32 at the nearest and farthest depth);
+//   B  stage that window into LDS as 8-byte cells {half(1024+R) | half(1024+G),
+//      half(1024+B) | raw depth} with 16-byte / 8-byte global loads;
+//   C  per pixel: project in float64 (the reference's operation order), gather
+//      the four taps from LDS, blend, accumulate; a tap outside the window
+//      (large parallax, a window cut at WIN_PITCH x WIN_ROWS) is gathered
+//      straight from global memory, so the prediction never affects results.
+// Predicates are 64-bit lane masks in scalar registers (one vector compare each,
+// combined and counted on the scalar unit).  Reduction: sums by DPP row
+// reductions, the four waves through LDS, then one float64 / uint32 atomic per
+// quantity per workgroup into the accumulators of the caller's workspace.  The
+// workgroup that draws the last ticket of an (image, neighbour) pair moves the
+// totals to the outputs with atomic exchanges, which also leaves the workspace
+// zeroed for the next call: no memset and no second kernel on the stream.
 constexpr int TILE_W = 128;
 constexpr int TILE_H = 16;
 constexpr int TPB = 256;
