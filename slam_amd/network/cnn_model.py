@@ -21,6 +21,7 @@ import torch
 
 from . import encoder_ops as ops
 from .model_config import get_config_provider
+from ..utils.time_utils import time_it
 
 # (name, output channels, max-pool after)   cnn_model.py:37-62
 CONV_LAYERS = (
@@ -464,6 +465,7 @@ class VGG16Model:
         self._apply_gradients(1.0 / dp.world_size())
         return self.loss
 
+    @time_it(drain_gpu=True)
     def start_training(self, max_steps):
         """cnn_model.py:175-181."""
         for _ in range(max_steps):

@@ -22,6 +22,7 @@ import numpy as np
 
 from .. import frame_pairs as fp
 from ..preprocess.geometry import _find_label
+from ..utils.time_utils import time_it
 
 
 def get_mean(rgb_images, channels=3):
@@ -182,6 +183,7 @@ class SimpleInputProvider:
         def __iter__(self):
             return self
 
+        @time_it
         def __next__(self):
             if self.counter >= self.sequence_length:
                 raise StopIteration()

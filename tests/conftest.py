@@ -9,6 +9,9 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# the timed calls (utils/time_utils.py) write timing.log into the working directory unless told otherwise
+os.environ.setdefault("SLAM_TIMING_LOG", "")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
