@@ -238,6 +238,8 @@ int slamhip_maxpool2_bwd(const void* x, const void* y, const void* dy, void* dx,
 /* Parameter casts / re-layouts into the operand forms above. */
 int slamhip_cast_f32_bf16(const float* src, void* dst, long long n, void* stream);
 int slamhip_transpose_cast_bf16(const float* src_rc, void* dst_cr, int R, int C, void* stream);
+/* The same re-layout from a bf16 source ([R][C] -> [C][R]). */
+int slamhip_transpose_bf16(const void* src_rc, void* dst_cr, int R, int C, void* stream);
 int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad, int Cin, int Cout,
                                 void* stream);
 
@@ -273,6 +275,12 @@ int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias,
 int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long long n, float lr,
                       float beta1, float beta2, float eps, int step, float grad_scale,
                       void* stream);
+/* The same update (cnn_model.py:146-160); in the same pass the first shadow_n updated
+ * parameters are also written as bf16 to shadow_bf16 (the operand copy of the fully
+ * connected weights, which lie first in the flat parameter buffer). */
+int slamhip_adam_step_shadow(float* param, const float* grad, float* m, float* v, long long n, float lr,
+                             float beta1, float beta2, float eps, int step, float grad_scale,
+                             void* shadow_bf16, long long shadow_n, void* stream);
 
 /* ---- device: input preparation of the RGB-D trainers --------------------------
  * slam/network/model_input.py:427-450 + :360-362,517-522 for a batch of raw frames

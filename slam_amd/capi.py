@@ -65,6 +65,7 @@ SIGNATURES = {
     "slamhip_maxpool2_bwd": ([_c_void_p] * 4 + [_c_int] * 4 + [_c_void_p], _c_int),
     "slamhip_cast_f32_bf16": ([_c_void_p, _c_void_p, ctypes.c_longlong, _c_void_p], _c_int),
     "slamhip_transpose_cast_bf16": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p], _c_int),
+    "slamhip_transpose_bf16": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_conv_weight_layouts": ([_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p], _c_int),
     "slamhip_l2loss": ([_c_void_p] * 5 + [_c_int] * 2 + [_c_void_p], _c_int),
     "slamhip_weighted_sq_loss": ([_c_void_p] * 3 + [ctypes.c_float] + [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p], _c_int),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "slamhip_pad_cast_bf16": ([_c_void_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_adam_step": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float,
                                                                                           _c_void_p], _c_int),
+    "slamhip_adam_step_shadow": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 +
+                                 [_c_int, ctypes.c_float, _c_void_p, ctypes.c_longlong, _c_void_p], _c_int),
 }
 
 _lib = None

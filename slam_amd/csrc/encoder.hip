@@ -1541,16 +1541,48 @@ cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long
 }
 
 // dst[c][r] = bf16(src[r][c]) for a row-major [R][Ccols] float matrix (32x32 LDS tiles)
+template <typename SrcT>
 __global__ void __launch_bounds__(256)
-transpose_cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int Ccols) {
+transpose_cast_kernel(const SrcT* __restrict__ src, bf16* __restrict__ dst, int R, int Ccols) {
   __shared__ float tile[32][33];
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
   for (int j = ty; j < 32; j += 8)
-    if (r0 + j < R && c0 + tx < Ccols) tile[j][tx] = src[(long long)(r0 + j) * Ccols + c0 + tx];
+    if (r0 + j < R && c0 + tx < Ccols) tile[j][tx] = (float)src[(long long)(r0 + j) * Ccols + c0 + tx];
   __syncthreads();
   for (int j = ty; j < 32; j += 8)
     if (c0 + j < Ccols && r0 + tx < R) dst[(long long)(c0 + j) * R + r0 + tx] = (bf16)tile[tx][j];
+}
+
+// bf16 [R][C] -> bf16 [C][R] in 64 x 64 tiles with 16-byte global accesses on both sides
+// (R and C multiples of 8, both bases 16-byte aligned); the 2-byte transpose happens in LDS
+__global__ void __launch_bounds__(256)
+transpose_bf16_kernel(const bf16* __restrict__ src, bf16* __restrict__ dst, int R, int Ccols) {
+  __shared__ bf16 tile[64][64 + 2];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int t = threadIdx.x, ch = t & 7;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int r = (t >> 3) + 32 * h;
+    if (r0 + r < R && c0 + ch * 8 < Ccols) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (long long)(r0 + r) * Ccols + c0 + ch * 8);
+      const bf16* e = reinterpret_cast<const bf16*>(&v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) tile[r][ch * 8 + q] = e[q];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = (t >> 3) + 32 * h;          // output row = source column
+    if (c0 + c < Ccols && r0 + ch * 8 < R) {
+      uint4 v;
+      bf16* e = reinterpret_cast<bf16*>(&v);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) e[q] = tile[ch * 8 + q][c];
+      *reinterpret_cast<uint4*>(dst + (long long)(c0 + c) * R + r0 + ch * 8) = v;
+    }
+  }
 }
 
 // conv filter HWIO [9][Cin][Cout] float -> forward operand [Cout][9*Cin] bf16 and
@@ -1628,9 +1660,12 @@ __global__ void posenet_loss_kernel(const float* __restrict__ out, const float* 
 // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)); grad_scale folds the 1/world
 // of the data-parallel mean
 // ---------------------------------------------------------------------------
+// shadow (optional): bf16 copy of the first shadow_n updated parameters, written in the same
+// pass (the fully connected weights' operand copy: saves reading them again for the cast)
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-            long long n, float lr_t, float beta1, float beta2, float eps, float grad_scale) {
+            long long n, float lr_t, float beta1, float beta2, float eps, float grad_scale,
+            bf16* __restrict__ shadow, long long shadow_n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const float gi = g[i] * grad_scale;
@@ -1638,7 +1673,9 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
   const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
   m[i] = mi;
   v[i] = vi;
-  p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+  const float pi = p[i] - lr_t * mi / (sqrtf(vi) + eps);
+  p[i] = pi;
+  if (i < shadow_n) shadow[i] = (bf16)pi;
 }
 
 // tf.train.GradientDescentOptimizer: p -= lr * g
@@ -2112,8 +2149,22 @@ int slamhip_cast_f32_bf16(const float* src, void* dst, long long n, void* stream
 
 int slamhip_transpose_cast_bf16(const float* src_rc, void* dst_cr, int R, int C, void* stream) {
   SLAMHIP_REQUIRE(src_rc && dst_cr && R > 0 && C > 0, SLAMHIP_E_ARG, "transpose_cast: bad argument");
-  hipLaunchKernelGGL(transpose_cast_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, (hipStream_t)stream,
-                     src_rc, (bf16*)dst_cr, R, C);
+  hipLaunchKernelGGL(transpose_cast_kernel<float>, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
+                     (hipStream_t)stream, src_rc, (bf16*)dst_cr, R, C);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_transpose_bf16(const void* src_rc, void* dst_cr, int R, int C, void* stream) {
+  SLAMHIP_REQUIRE(src_rc && dst_cr && R > 0 && C > 0, SLAMHIP_E_ARG, "transpose_bf16: bad argument");
+  const bool vec = R % 8 == 0 && C % 8 == 0 && reinterpret_cast<uintptr_t>(src_rc) % 16 == 0 &&
+                   reinterpret_cast<uintptr_t>(dst_cr) % 16 == 0;
+  if (vec)
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((C + 63) / 64, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)src_rc, (bf16*)dst_cr, R, C);
+  else
+    hipLaunchKernelGGL(transpose_cast_kernel<bf16>, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16*)src_rc, (bf16*)dst_cr, R, C);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -2182,7 +2233,21 @@ int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long 
   if (n == 0) return SLAMHIP_OK;
   const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
-                     beta1, beta2, eps, grad_scale);
+                     beta1, beta2, eps, grad_scale, (bf16*)nullptr, 0LL);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_adam_step_shadow(float* param, const float* grad, float* m, float* v, long long n, float lr, float beta1,
+                             float beta2, float eps, int step, float grad_scale, void* shadow_bf16,
+                             long long shadow_n, void* stream) {
+  SLAMHIP_REQUIRE(param && grad && m && v && n >= 0 && step >= 1, SLAMHIP_E_ARG, "adam_step_shadow: bad argument");
+  SLAMHIP_REQUIRE(shadow_n >= 0 && shadow_n <= n && (shadow_bf16 || shadow_n == 0), SLAMHIP_E_ARG,
+                  "adam_step_shadow: shadow of %lld elements for %lld parameters", shadow_n, n);
+  if (n == 0) return SLAMHIP_OK;
+  const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
+                     beta1, beta2, eps, grad_scale, (bf16*)shadow_bf16, shadow_n);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

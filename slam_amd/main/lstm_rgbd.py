@@ -116,7 +116,7 @@ def evaluate_model(data_dir=None, passes=10, sequence_length=400, weights_file=L
     network = build_complete_network(rgbd_input_batch, groundtruth_batch, lstm_init_state, batch_size, lstm_layers,
                                      cnn_output_dim, config_provider.normalization_epsilon(), **encoder_options)
     lstm_model, lstm_output = network[2], network[3]
-    checkpoint.restore(weights_file, lstm_model.named_variables())
+    checkpoint.restore(weights_file, lstm_model.named_variables(), models=(network[0],))
 
     total_rmse = 0
     for step in range(passes):

@@ -17,9 +17,11 @@ def save(filename, named_variables, global_step=None):
     os.replace(tmp, filename)
 
 
-def restore(filename, named_variables):
+def restore(filename, named_variables, models=()):
     """Copies every saved tensor into the variable of the same name; a variable without
-    a saved value, or a shape mismatch, is an error (as Saver.restore).  Returns the saved
+    a saved value, or a shape mismatch, is an error (as Saver.restore).  `models`: the
+    networks that own the variables; each is told that its parameters changed, so that
+    derived copies (bf16 operands) are rebuilt before its next forward.  Returns the saved
     global step or None."""
     payload = torch.load(filename, map_location="cpu", weights_only=True)
     for name, var in named_variables.items():
@@ -29,5 +31,7 @@ def restore(filename, named_variables):
             raise ValueError("%s: variable %r has shape %s, saved %s" %
                              (filename, name, tuple(var.shape), tuple(payload[name].shape)))
         var.copy_(payload[name])
+    for m in models:
+        m.parameters_changed()
     step = payload.get("global_step")
     return None if step is None else int(step)

@@ -170,11 +170,14 @@ class VGG16Model:
         for name, ci, co in conv_shapes[1:]:
             self._w_fwd[name] = torch.empty(co, 9 * ci, **bf)
             self._w_dgrad[name] = torch.empty(ci, 9 * co, **bf)
+        # the fully connected parameters lie first in the flat buffer: one bf16 shadow of that
+        # range holds their [in][out] operands (written by the Adam kernel as it updates them)
+        self._fc_shadow = torch.empty(self._fc_end, **bf)
         for name in ("fc6-conv", "fc7-conv", "out_layer"):
             k_in, n_out = self.params[name + "/weights"].shape
             self._w_fwd[name] = torch.empty(n_out, k_in, **bf)      # [out][in]
-            self._w_dgrad[name] = torch.empty(k_in, n_out, **bf)    # [in][out]
-        self._operands_stale = True
+            self._w_dgrad[name] = self._view(self._fc_shadow, name + "/weights")    # [in][out]
+        self.parameters_changed()
 
         # ---- activations
         f32 = dict(dtype=torch.float32, device=dev)
@@ -248,14 +251,21 @@ class VGG16Model:
         raise NotImplementedError("layers are fixed by build_graph()")
 
     # ---------------------------------------------------------------- forward
+    def parameters_changed(self):
+        """To be called after the parameters were written from outside (initialisation, a restored
+        checkpoint, a hand-made update): the bf16 operand copies are rebuilt before the next forward."""
+        self._operands_stale = True
+        self._fc_shadow_fresh = False
+
     def _refresh_operands(self):
         for a in self._act[1:]:
             n = a["name"]
             ops.conv_weight_layouts(self.params[n + "/weights"], self._w_fwd[n], self._w_dgrad[n])
+        if not self._fc_shadow_fresh:
+            ops.cast_bf16(self.flat_params[:self._fc_end], self._fc_shadow)
+            self._fc_shadow_fresh = True
         for n in ("fc6-conv", "fc7-conv", "out_layer"):
-            w = self.params[n + "/weights"]
-            ops.transpose_cast(w, self._w_fwd[n])
-            ops.cast_bf16(w, self._w_dgrad[n])
+            ops.transpose_bf16(self._w_dgrad[n], self._w_fwd[n])
         self._operands_stale = False
 
     def forward(self):
@@ -421,13 +431,15 @@ class VGG16Model:
         lr = o.learning_rate(self.global_step) if callable(o.learning_rate) else o.learning_rate
         if o.kind == 'AdamOptimizer':
             ops.adam_step(self.flat_params, self.flat_grads, self._adam_m, self._adam_v, lr,
-                          step=self.global_step + 1, grad_scale=grad_scale)
+                          step=self.global_step + 1, grad_scale=grad_scale, shadow=self._fc_shadow)
+            self._operands_stale, self._fc_shadow_fresh = True, True
         elif o.kind == 'GradientDescentOptimizer':
             ops.sgd_step(self.flat_params, self.flat_grads, lr, grad_scale=grad_scale)
+            self.parameters_changed()
         else:
             ops.rmsprop_step(self.flat_params, self.flat_grads, self._rms, lr, grad_scale=grad_scale)
+            self.parameters_changed()
         self.global_step += 1
-        self._operands_stale = True
 
     def set_output_gradient(self, d_output):
         """d loss / d network_output from a head built on this encoder's output
@@ -454,7 +466,7 @@ class VGG16Model:
         """Plain gradient descent on every parameter (the update a head's optimizer applies
         to the encoder, slam/network/lstm_model.py:63-66)."""
         ops.sgd_step(self.flat_params, self.flat_grads, learning_rate, grad_scale=grad_scale)
-        self._operands_stale = True
+        self.parameters_changed()
 
     def train_step(self):
         """forward, loss, backward, gradient mean over the data-parallel ranks, update."""

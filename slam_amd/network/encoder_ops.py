@@ -185,6 +185,13 @@ def transpose_cast(src, dst):
     _call("slamhip_transpose_cast_bf16", capi.ptr(src), capi.ptr(dst), R, C)
 
 
+def transpose_bf16(src, dst):
+    """bf16 [R][C] -> bf16 [C][R]."""
+    R, C = _chk(src, BF16, "src").shape
+    assert _chk(dst, BF16, "dst").shape == (C, R)
+    _call("slamhip_transpose_bf16", capi.ptr(src), capi.ptr(dst), R, C)
+
+
 def l2loss(out, gt, loss_weight, loss, d_out=None):
     B, D = _chk(out, F32, "out").shape
     assert _chk(gt, F32, "gt").shape == (B, D) and _chk(loss_weight, F32, "loss_weight").shape == (D, D)
@@ -194,12 +201,19 @@ def l2loss(out, gt, loss_weight, loss, d_out=None):
     _call("slamhip_l2loss", capi.ptr(out), capi.ptr(gt), capi.ptr(loss_weight), capi.ptr(loss), capi.ptr(d_out), B, D)
 
 
-def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, shadow=None):
+    """One Adam update of the flat parameter buffer.  `shadow` (bf16, at most as long as
+    `param`) receives the updated leading parameters as bf16 in the same pass."""
     n = _chk(param, F32, "param").numel()
     for t in (grad, m, v):
         assert _chk(t, F32, "adam tensor").numel() == n
-    _call("slamhip_adam_step", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, float(lr), float(beta1),
-          float(beta2), float(eps), int(step), float(grad_scale))
+    if shadow is None:
+        _call("slamhip_adam_step", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, float(lr),
+              float(beta1), float(beta2), float(eps), int(step), float(grad_scale))
+    else:
+        assert _chk(shadow, BF16, "shadow").numel() <= n
+        _call("slamhip_adam_step_shadow", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, float(lr),
+              float(beta1), float(beta2), float(eps), int(step), float(grad_scale), capi.ptr(shadow), shadow.numel())
 
 
 def sgd_step(param, grad, lr, grad_scale=1.0):

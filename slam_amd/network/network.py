@@ -233,6 +233,11 @@ class Network:
             self.total_weights += w.numel() + e['c_o']
         self._operands_stale = True
 
+    def parameters_changed(self):
+        """To be called after the parameters were written from outside (a restored checkpoint, a
+        hand-made update): the bf16 operand copies are rebuilt before the next forward."""
+        self._operands_stale = True
+
     def _real_c_in(self, e, g):
         """Channels of the layer's input that carry data (the padded network input has fewer)."""
         if e['input'] == 'data' and e['op'] == 'conv':

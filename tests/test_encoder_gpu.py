@@ -398,3 +398,36 @@ def test_filter_row_convolution_kernel(ops, B, H, W, C, N):
     dx = torch.empty(B, H, W, C, dtype=BF, device="cuda")
     ops.conv3x3(dyd, w_dg, out_bf16=dx, flip=True)
     close(dx, x.grad)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("R,C", [(128, 64), (25088 // 8, 4096 // 8), (200, 72), (37, 19)])
+def test_transpose_bf16(ops, R, C):
+    """bf16 [R][C] -> [C][R]: the 16-byte path (R, C multiples of 8) and the ragged fallback."""
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    src = torch.randn(R, C, generator=g).to(torch.bfloat16).cuda()
+    dst = torch.zeros(C, R, dtype=torch.bfloat16, device="cuda")
+    ops.transpose_bf16(src, dst)
+    torch.cuda.synchronize()
+    assert torch.equal(dst.cpu(), src.cpu().t().contiguous())
+
+
+@pytest.mark.gpu
+def test_adam_shadow_matches_plain_update(ops):
+    """The shadow-writing Adam step updates exactly as the plain one and leaves bf16(p) of the
+    leading parameters in the shadow; the rest of the shadow buffer is not touched."""
+    n, ns = 10_000, 6_400
+    g = torch.Generator().manual_seed(5)
+    p0 = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g)
+    pa, pb = p0.clone().cuda(), p0.clone().cuda()
+    ma, va = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    mb, vb = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    shadow = torch.full((ns + 64,), 7.0, dtype=torch.bfloat16, device="cuda")
+    for step in (1, 2, 3):
+        ops.adam_step(pa, grad.cuda(), ma, va, lr=0.01, step=step, grad_scale=0.5)
+        ops.adam_step(pb, grad.cuda(), mb, vb, lr=0.01, step=step, grad_scale=0.5, shadow=shadow[:ns])
+    torch.cuda.synchronize()
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+    assert torch.equal(shadow[:ns].cpu(), pb[:ns].to(torch.bfloat16).cpu())
+    assert bool((shadow[ns:] == 7.0).all())
