@@ -1188,11 +1188,18 @@ stat_finish_kernel(const float* __restrict__ part, float* __restrict__ sums, int
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N2) return;
   const int chunk = (R + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * chunk, r1 = min(R, r0 + chunk);
-  float a0 = 0.f, a1 = 0.f;
+  // eight independent loads in flight per thread: the walk is latency-bound otherwise
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int r = r0;
-  for (; r + 1 < r1; r += 2) { a0 += part[(long long)r * N2 + c]; a1 += part[(long long)(r + 1) * N2 + c]; }
-  if (r < r1) a0 += part[(long long)r * N2 + c];
-  if (r0 < r1) atomicAdd(&sums[c], a0 + a1);
+  for (; r + 7 < r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(long long)(r + j) * N2 + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += v[j];
+  }
+  for (; r < r1; ++r) a[0] += part[(long long)r * N2 + c];
+  if (r0 < r1) atomicAdd(&sums[c], ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
 }
 
 // Both element-wise batch-norm kernels walk the tensor with a stride that is a multiple of C
@@ -1277,16 +1284,24 @@ bias_act_fwd_kernel(const float* __restrict__ z, const float* __restrict__ bias,
 __global__ void __launch_bounds__(256)
 bias_act_bwd_kernel(const float* __restrict__ dy, const bf16* __restrict__ y, bf16* __restrict__ dz,
                     float* __restrict__ dbias, int M, int N, int relu) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  // 64 columns x 4 row groups per workgroup: a thread walks every fourth row (loads of eight
+  // rows in flight), the four partial column sums meet in LDS
+  __shared__ float part[4][64];
+  const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + col;
   float s = 0.f;
-  for (int m = 0; m < M; ++m) {
-    const long long o = (long long)m * N + n;
-    const float g = (!relu || (float)y[o] > 0.0f) ? dy[o] : 0.0f;
-    dz[o] = (bf16)g;
-    s += g;
+  if (n < N) {
+#pragma unroll 8
+    for (int m = rg; m < M; m += 4) {
+      const long long o = (long long)m * N + n;
+      const float g = (!relu || (float)y[o] > 0.0f) ? dy[o] : 0.0f;
+      dz[o] = (bf16)g;
+      s += g;
+    }
   }
-  dbias[n] = s;
+  part[rg][col] = s;
+  __syncthreads();
+  if (rg == 0 && n < N) dbias[n] = (part[0][col] + part[1][col]) + (part[2][col] + part[3][col]);
 }
 
 // y = relu(z + bias) on NHWC bfloat16 (the convolution layer without batch-norm,
@@ -2109,7 +2124,7 @@ int slamhip_bias_act_bwd(const float* dy, const void* y_bf16, void* dz_bf16, flo
                          void* stream) {
   SLAMHIP_REQUIRE(dy && dz_bf16 && dbias && (y_bf16 || !relu) && M >= 0 && N > 0, SLAMHIP_E_ARG,
                   "bias_act_bwd: bad argument");
-  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(blocks_for(N, 64)), dim3(64), 0, (hipStream_t)stream, dy,
+  hipLaunchKernelGGL(bias_act_bwd_kernel, dim3(blocks_for(N, 64)), dim3(256), 0, (hipStream_t)stream, dy,
                      (const bf16*)y_bf16, (bf16*)dz_bf16, dbias, M, N, relu);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
