@@ -889,6 +889,145 @@ wgrad_rows64_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, flo
 }
 
 // ---------------------------------------------------------------------------
+// The same filter-row scheme for narrow images (W + 2 <= 128): a K-step is a GROUP of G whole
+// image rows, laid out in LDS with a pitch of W + 2 entries per row (dY: W pixels then two
+// zeros; X: zero, W pixels, zero), G (W + 2) <= 128, the rest of the 128 entries zero.  With
+// that pitch the X entry of tap dx for dY entry k is entry k + dx + 1 in every row of the group,
+// and the zero halo entries stand for the pixels left and right of the image.  112 of the 128
+// K entries carry pixels at W = 56, 28 and 14.  A workgroup owns one filter row of a TM x 64
+// (ci x co) tile.
+// ---------------------------------------------------------------------------
+template <int TM>
+__global__ void __launch_bounds__(256)
+wgrad_rowgroup_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int BH, int H,
+                      int W, int Cin, int Cout, int G, int splitk, int total_work) {
+  constexpr int KS = 128, PX = TM + 32, PY = 64 + 32, MT = TM / 64;
+  constexpr int XT = TM / 16;                    // threads per X row (16 channels each)
+  constexpr int XR = 256 / XT;                   // X rows per loader pass
+  constexpr int XPASS = (KS + 2 + XR - 1) / XR;
+  __shared__ __attribute__((aligned(16))) bf16 Xs[(KS + 2) * PX];
+  __shared__ __attribute__((aligned(16))) bf16 Ys[KS * PY];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int per_xcd = (total_work + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_work) return;
+  const int ci_tiles = Cin / TM, co_tiles = Cout / 64, tiles = 3 * ci_tiles * co_tiles;
+  const int slice = work / tiles;
+  int rest = work - slice * tiles;
+  const int dyi = rest / (ci_tiles * co_tiles);            // filter row 0..2  (dy = dyi - 1)
+  rest -= dyi * ci_tiles * co_tiles;
+  const int ci0 = (rest / co_tiles) * TM, co0 = (rest % co_tiles) * 64;
+  const int S = (BH + G - 1) / G;                            // K-steps: groups of G image rows
+  const int chunk = (S + splitk - 1) / splitk;
+  const int s_begin = slice * chunk, s_end = min(S, s_begin + chunk);
+  if (s_begin >= s_end) return;
+
+  // loader geometry, fixed per thread: tile entry -> (row of the group, pixel of the row)
+  const int RS = W + 2;
+  const int x_row = tid / XT, x_q = tid % XT;
+  int x_grp[XPASS], x_off[XPASS], x_y[XPASS];
+  bool x_in[XPASS];
+#pragma unroll
+  for (int i = 0; i < XPASS; ++i) {
+    const int j = x_row + XR * i, grp = j / RS, px = j - grp * RS - 1;
+    x_grp[i] = grp;
+    x_off[i] = grp * W + px;
+    x_in[i] = j < G * RS && (unsigned)px < (unsigned)W;
+    x_y[i] = (s_begin * G + grp) % H;               // image row of this entry within its image
+  }
+  const int y_row = tid >> 2, y_q = tid & 3;
+  int y_grp[2], y_off[2];
+  bool y_in[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = y_row + 64 * i, grp = j / RS, px = j - grp * RS;
+    y_grp[i] = grp;
+    y_off[i] = grp * W + px;
+    y_in[i] = j < G * RS && px < W;
+  }
+  const bf16* x_col = X + ci0 + x_q * 16;
+  const bf16* y_col = dY + co0 + y_q * 16;
+  const int g_mod = G % H;
+
+  f32x16 acc[3][MT];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][i][r] = 0.0f;
+  uint4 rx[XPASS][2], ry[2][2];
+  uint32_t keep_x[XPASS], keep_y[2];
+
+  // rows that do not exist read pixel 0 and are zeroed by mask on the way into LDS
+#define SLAMHIP_WGROUP_ISSUE(step)                                                                  \
+  {                                                                                                 \
+    const int R0 = (step) * G;                                                                      \
+    _Pragma("unroll") for (int i = 0; i < XPASS; ++i) {                                             \
+      const int ys = x_y[i] + dyi - 1;                                                              \
+      const bool ok = x_in[i] && R0 + x_grp[i] < BH && (unsigned)ys < (unsigned)H;                  \
+      const long long px = ok ? ((long long)(R0 + dyi - 1) * W + x_off[i]) : 0;                     \
+      const uint4* xs = reinterpret_cast<const uint4*>(x_col + px * Cin);                           \
+      rx[i][0] = xs[0]; rx[i][1] = xs[1];                                                           \
+      keep_x[i] = ok ? 0xffffffffu : 0u;                                                            \
+      x_y[i] += g_mod;                                                                              \
+      if (x_y[i] >= H) x_y[i] -= H;                                                                 \
+    }                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                 \
+      const bool ok = y_in[i] && R0 + y_grp[i] < BH;                                                \
+      const long long py = ok ? ((long long)R0 * W + y_off[i]) : 0;                                 \
+      const uint4* ysrc = reinterpret_cast<const uint4*>(y_col + py * Cout);                        \
+      ry[i][0] = ysrc[0]; ry[i][1] = ysrc[1];                                                       \
+      keep_y[i] = ok ? 0xffffffffu : 0u;                                                            \
+    }                                                                                               \
+  }
+
+  SLAMHIP_WGROUP_ISSUE(s_begin);
+  for (int step = s_begin; step < s_end; ++step) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < XPASS; ++i) {
+      const int j = x_row + XR * i;
+      if (j < KS + 2) {
+        uint4* xd = reinterpret_cast<uint4*>(&Xs[j * PX + x_q * 16]);
+        xd[0] = and4(rx[i][0], keep_x[i]); xd[1] = and4(rx[i][1], keep_x[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      uint4* yd = reinterpret_cast<uint4*>(&Ys[(y_row + 64 * i) * PY + y_q * 16]);
+      yd[0] = and4(ry[i][0], keep_y[i]); yd[1] = and4(ry[i][1], keep_y[i]);
+    }
+    __syncthreads();
+    if (step + 1 < s_end) SLAMHIP_WGROUP_ISSUE(step + 1);
+#pragma unroll
+    for (int kk = 0; kk < KS; kk += 16) {
+      const bf16x8 bfr = tr_frag<PY>(Ys, kk, wn * 32, lane);              // B[k = entry][n = co]
+#pragma unroll
+      for (int t = 0; t < 3; ++t)                                          // tap dx = t - 1: X entry k + t
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const bf16x8 af = tr_frag<PX>(Xs, kk + t, wm * (TM / 2) + i * 32, lane);   // A[m = ci][k = entry]
+          acc[t][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, acc[t][i], 0, 0, 0);
+        }
+    }
+  }
+#undef SLAMHIP_WGROUP_ISSUE
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * 32 + (lane & 31);
+        atomicAdd(&dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co], acc[t][i][r]);
+      }
+}
+
+// ---------------------------------------------------------------------------
 // first layer (Cin = 4, K = 36): too thin for the matrix cores, 0.8 % of the FLOPs
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
@@ -1926,6 +2065,34 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
                        (const bf16*)dy, dw, B, H, W, Cin, Cout, (int)split, (int)total3);
     SLAMHIP_HIP(hipGetLastError());
     return SLAMHIP_OK;
+  }
+  // narrow images (56, 28, 14 wide here): groups of whole image rows per K-step, see the kernel.
+  // SLAMHIP_WGRAD_ROWGROUP = 0 turns it off, otherwise it is the number of workgroups aimed at.
+  static const int rowgroup = [] { const char* e = getenv("SLAMHIP_WGRAD_ROWGROUP"); return e ? atoi(e) : 512; }();
+  if (rowgroup && taps == 9 && W + 2 <= 128 && P > 0) {
+    const int G = 128 / (W + 2);
+    const long long BH = (long long)B * H;
+    if (G * W >= 96 && BH >= G) {                          // at least three quarters of a K-step carry pixels
+      const int TMg = Cin % 128 == 0 ? 128 : 64;
+      const long long tiles3 = 3LL * (Cin / TMg) * (Cout / 64);
+      const long long S = (BH + G - 1) / G;
+      long long split = rowgroup / tiles3;
+      if (split > S / 8) split = S / 8;                 // at least 8 K-steps per slice
+      if (split < 1) split = 1;
+      const long long chunk = (S + split - 1) / split;
+      split = (S + chunk - 1) / chunk;
+      SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+      const long long total3 = tiles3 * split;
+      const dim3 grid3((unsigned)((total3 + 7) / 8 * 8));
+      if (TMg == 128)
+        hipLaunchKernelGGL(wgrad_rowgroup_kernel<128>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw,
+                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3);
+      else
+        hipLaunchKernelGGL(wgrad_rowgroup_kernel<64>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw,
+                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3);
+      SLAMHIP_HIP(hipGetLastError());
+      return SLAMHIP_OK;
+    }
   }
   const int TM = Cin % 128 == 0 ? 128 : 64, TN = Cout % 128 == 0 ? 128 : 64;
   const long long tiles = (long long)(Cin / TM) * (Cout / TN) * taps;

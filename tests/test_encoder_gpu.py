@@ -92,6 +92,21 @@ def test_wgrad_row_segment_kernel(ops, B, H, W, C, N):
     close(dw, w.grad, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,W,C,N", [(2, 56, 56, 128, 64), (3, 28, 28, 64, 128), (3, 14, 14, 256, 64),
+                                       (1, 3, 28, 64, 64), (40, 14, 14, 128, 128), (5, 1, 30, 64, 64)])
+def test_wgrad_row_group_kernel(ops, B, H, W, C, N):
+    """Narrow images: the filter-row kernel whose K-step is a group of whole image rows laid out
+    with zero halo entries; 64- and 128-channel tiles, a last group that is not full, images of a
+    single row (no rows above or below), groups spanning several images, many slices."""
+    x = rnd(B, H, W, C, seed=93).requires_grad_()
+    w = rnd(3, 3, C, N, seed=94, scale=0.05).requires_grad_()
+    dy = rnd(B, H, W, N, seed=95)
+    conv_ref(x, w).backward(dy)
+    dw = torch.full((3, 3, C, N), 7.0, dtype=torch.float32, device="cuda")
+    ops.wgrad(x.detach().cuda().to(BF), dy.cuda().to(BF), dw)
+    close(dw, w.grad, rtol=2e-3)
+
+
 @pytest.mark.parametrize("M,N,K", [(5, 6, 128), (130, 256, 192), (128, 64, 64), (1, 4096, 256)])
 def test_gemm_nt_and_fc_wgrad(ops, M, N, K):
     a, b = rnd(M, K, seed=7), rnd(N, K, seed=8, scale=0.1)
