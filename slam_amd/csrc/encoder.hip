@@ -369,6 +369,165 @@ igemm_row3_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, 
 }
 
 // ---------------------------------------------------------------------------
+// The filter-row kernel with 256 x 64 tiles: four waves stacked along the pixels, 64 x 64
+// outputs each (two A and two B fragments feed four MFMAs: 1 KB of LDS reads per MFMA against
+// 1.5 KB with the 64 x 32 wave tiles above, which bound the 64-channel layers).  One record of
+// column statistics per wave, i.e. two per 128 pixel rows as the other kernels leave.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
+                        int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
+                        float* __restrict__ stat_part) {
+  constexpr int BM = 256, BN = 64, AR = BM + 2;
+  constexpr int NBV = 3 * BN / 32;            // 16-byte B loads per thread and step
+  __shared__ __attribute__((aligned(16))) bf16 As[AR * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 Bs[3 * BN * LDS_PITCH];
+
+  const int per_xcd = (total_tiles + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_tiles) return;
+  const int m0 = (work / n_tiles) * BM, n0 = (work % n_tiles) * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  const int Ktot = 9 * C;
+
+  // A loader: thread -> staged row tid (pixel m0 - 1 + row), all 128 bytes of the 64 channels;
+  // threads 0..15 also fetch one 16-byte chunk of the two extra rows 256, 257
+  const int h_row = BM + (tid >> 3), h_chunk = tid & 7;
+  const bool has_halo = tid < 16;
+  const bf16* b_src[NBV];
+  int b_dst[NBV];
+#pragma unroll
+  for (int v = 0; v < NBV; ++v) {
+    const int id = tid + 256 * v, e = id / (BN * 8), rem = id - e * (BN * 8), n = rem >> 3, ch = rem & 7;
+    b_src[v] = Bw + (long long)(n0 + n) * Ktot + e * C + ch * 8;
+    b_dst[v] = (e * BN + n) * LDS_PITCH + ch * 8;
+  }
+
+  // validity of the nine taps of this lane's two fragment rows (pixels)
+  unsigned int fm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    unsigned int mask = 0u;
+    if (m < M) {
+      const int rem = m % (H * W);
+      const int y = rem / W, x = rem - y * W;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(y + t / 3 - 1) < (unsigned)H && (unsigned)(x + t % 3 - 1) < (unsigned)W) mask |= 1u << t;
+    }
+    fm[i] = mask;
+  }
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  const int chunks = C / 64, ksteps = 3 * chunks;
+  uint4 ra[8], rah, rb[NBV];
+  int g = 0, c0 = 0;     // filter row and channel chunk of the loads in flight
+  rah = make_uint4(0u, 0u, 0u, 0u);
+  const uint32_t b_keep = n0 < N ? 0xffffffffu : 0u;   // always set; the masked copy keeps the staged values in registers
+
+#define SLAMHIP_ROW3W_ISSUE()                                                                    \
+  {                                                                                              \
+    const int dy = (flip ? 2 - g : g) - 1;                                                       \
+    long long q = (long long)m0 - 1 + tid + (long long)dy * W;                                   \
+    q = q < 0 ? 0 : (q > M - 1 ? M - 1 : q);                                                     \
+    const uint4* src = reinterpret_cast<const uint4*>(A + q * C + c0);                           \
+    _Pragma("unroll") for (int v = 0; v < 8; ++v) ra[v] = src[v];                                \
+    if (has_halo) {                                                                              \
+      long long qh = (long long)m0 - 1 + h_row + (long long)dy * W;                              \
+      qh = qh < 0 ? 0 : (qh > M - 1 ? M - 1 : qh);                                               \
+      rah = *reinterpret_cast<const uint4*>(A + qh * C + c0 + h_chunk * 8);                      \
+    }                                                                                            \
+    _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
+      rb[v] = *reinterpret_cast<const uint4*>(b_src[v] + g * 3 * C + c0);                        \
+    c0 += 64;                                                                                    \
+    if (c0 == C) { c0 = 0; ++g; }                                                                \
+  }
+
+  int g_cur = 0, c_cur = 0;   // position of the step being computed
+  SLAMHIP_ROW3W_ISSUE();
+  for (int s = 0; s < ksteps; ++s) {
+    __syncthreads();   // the previous step's fragments have been read
+    {
+      uint4* dst = reinterpret_cast<uint4*>(&As[tid * LDS_PITCH]);
+#pragma unroll
+      for (int v = 0; v < 8; ++v) dst[v] = and4(ra[v], b_keep);
+      if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah;
+    }
+#pragma unroll
+    for (int v = 0; v < NBV; ++v) *reinterpret_cast<uint4*>(&Bs[b_dst[v]]) = and4(rb[v], b_keep);
+    __syncthreads();
+    if (s + 1 < ksteps) SLAMHIP_ROW3W_ISSUE();   // in flight while the matrix cores work
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      const int t = flip ? 8 - (g_cur * 3 + e) : g_cur * 3 + e;     // geometric tap of weight slot (g_cur, e)
+      const int shift = flip ? 2 - e : e;                           // staged row = pixel row + 1 + dx
+      uint32_t keep[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) keep[i] = ((fm[i] >> t) & 1u) ? 0xffffffffu : 0u;
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 16) {
+        bf16x8 af[2], bfr[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const uint4 raw = *reinterpret_cast<const uint4*>(
+              &As[(wm * 64 + i * 32 + (lane & 31) + shift) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+          af[i] = __builtin_bit_cast(bf16x8, and4(raw, keep[i]));
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(
+              &Bs[(e * BN + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    c_cur += 64;
+    if (c_cur == C) { c_cur = 0; ++g_cur; }
+  }
+#undef SLAMHIP_ROW3W_ISSUE
+
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int n = n0 + j * 32 + (lane & 31);
+        if (m < M && n < N) out_bf16[(long long)m * N + n] = (bf16)acc[i][j][r];
+      }
+  // records are counted in 64-row groups, two per 128 pixel rows; a wave wholly beyond the last
+  // 128-row tile holds zeros and leaves no record
+  if (stat_part && m0 / 64 + wm < (M + 127) / 128 * 2) {
+    float* part = stat_part + ((long long)(work / n_tiles) * 4 + wm) * 2 * N;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      float sm = 0.f, sq = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (float)(bf16)acc[i][j][r];
+          sm += v;
+          sq = __builtin_fmaf(v, v, sq);
+        }
+      store_column_stats(sm, sq, part, n0 + j * 32 + (lane & 31), N, lane);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // The same implicit GEMM with 256 x 256 tiles for wide layers (N % 256 == 0): eight waves
 // (2 x 4, 128 x 64 outputs each), both operand tiles of a K-step brought from global memory
 // straight into LDS by global_load_lds_dwordx4 (no staging registers, no ds_write), two
@@ -1947,10 +2106,18 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
     return records;
   }
   // many pixels, few channels, 64-wide output (bfloat16 only): one K-step per filter row
-  static const int row3 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3"); return e ? atoi(e) : 1; }();
+  // (SLAMHIP_IGEMM_ROW3: 0 off, 1 the 128 x 64 tiles, 2 the 256 x 64 tiles)
+  static const int row3 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3"); return e ? atoi(e) : 2; }();
   // (measured at batch 128: 224 x 224 x 64 -> 64 forward 940 -> 901 us, data gradient 847 -> 800 us;
-  // 112 x 112 x 128 -> 64 data gradient 434 -> 372 us; no gain with 128-wide output tiles)
+  // 112 x 112 x 128 -> 64 data gradient 434 -> 372 us; no gain with 128-wide output tiles; the
+  // 256 x 64 tiles another 4-5 % at 224 x 224 and nothing at 112 x 112)
   if (row3 && out_bf16 && !out_f32 && N % 64 == 0 && N % 128 != 0 && C <= 128 && M >= 128 * 1024) {
+    if (row3 == 2) {   // 256 x 64 tiles, 64 x 64 per wave
+      const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 64, total = m_tiles * n_tiles;
+      hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
+                         (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part);
+      return (M + 127) / 128 * 2;
+    }
     const int m_tiles = (int)((M + 127) / 128), n_tiles = N / 64, total = m_tiles * n_tiles;
     hipLaunchKernelGGL((igemm_row3_bf16_kernel<64>), dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
                        (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, 0);
