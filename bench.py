@@ -173,6 +173,7 @@ def main():
                                    % ("RCCL gradient all-reduce, " if dist is not None else "", enc["batch_per_gpu"]),
                        "images_per_s": world * enc["batch_per_gpu"] / (enc["step_ms"] * 1e-3),
                        "step_ms": enc["step_ms"], "steps": a.encoder_steps,
+                       "fwd_bwd_ms": enc["fwd_bwd_ms"], "forward_ms": enc["forward_ms"],
                        "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                     "frac": tfl / peak, "flops": "model FLOPs of the whole step / step time, per GPU"}}
             if world == 1 and rank == 0 and a.cpu_seconds > 0:

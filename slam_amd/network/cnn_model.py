@@ -77,8 +77,27 @@ def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, 
     e1.record()
     torch.cuda.synchronize()
     step_ms = e0.elapsed_time(e1) / max(1, steps)
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(steps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / max(1, steps)
+
+    def forward_backward():     # the step without the update (and without the all-reduce)
+        model.forward()
+        model.compute_loss(with_gradient=True)
+        model.backward()
+
+    fwd_bwd_ms = timed(forward_backward)
+    forward_ms = timed(model.forward)
     _, flops = model_flops(batch, height, width, 4, model.fc_dim, 6)
-    return dict(batch_per_gpu=batch, step_ms=step_ms, images_per_s_per_gpu=batch / (step_ms * 1e-3),
+    return dict(batch_per_gpu=batch, step_ms=step_ms, fwd_bwd_ms=fwd_bwd_ms, forward_ms=forward_ms,
+                images_per_s_per_gpu=batch / (step_ms * 1e-3),
                 tflop_per_step=flops / 1e12, achieved_tflops_per_gpu=flops / 1e12 / (step_ms * 1e-3),
                 loss=float(model.loss), parameters=int(model.total_weights))
 
