@@ -429,84 +429,97 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
   const int chunks = C / 64, ksteps = 3 * chunks;
-  uint4 ra[8], rah, rb[NBV];
-  int g = 0, c0 = 0;     // filter row and channel chunk of the loads in flight
-  rah = make_uint4(0u, 0u, 0u, 0u);
+  // two register sets: the loads of two K-steps are in flight (a tile has as few as three steps,
+  // and one step's MFMAs are shorter than a trip to HBM under load)
+  uint4 ra[2][8], rah[2], rb[2][NBV];
+  int g = 0, c0 = 0;     // filter row and channel chunk of the next loads to issue
+  rah[0] = rah[1] = make_uint4(0u, 0u, 0u, 0u);
   const uint32_t b_keep = n0 < N ? 0xffffffffu : 0u;   // always set; the masked copy keeps the staged values in registers
 
-#define SLAMHIP_ROW3W_ISSUE()                                                                    \
+#define SLAMHIP_ROW3W_ISSUE(set)                                                                 \
   {                                                                                              \
     const int dy = (flip ? 2 - g : g) - 1;                                                       \
     long long q = (long long)m0 - 1 + tid + (long long)dy * W;                                   \
     q = q < 0 ? 0 : (q > M - 1 ? M - 1 : q);                                                     \
     const uint4* src = reinterpret_cast<const uint4*>(A + q * C + c0);                           \
-    _Pragma("unroll") for (int v = 0; v < 8; ++v) ra[v] = src[v];                                \
+    _Pragma("unroll") for (int v = 0; v < 8; ++v) ra[set][v] = src[v];                           \
     if (has_halo) {                                                                              \
       long long qh = (long long)m0 - 1 + h_row + (long long)dy * W;                              \
       qh = qh < 0 ? 0 : (qh > M - 1 ? M - 1 : qh);                                               \
-      rah = *reinterpret_cast<const uint4*>(A + qh * C + c0 + h_chunk * 8);                      \
+      rah[set] = *reinterpret_cast<const uint4*>(A + qh * C + c0 + h_chunk * 8);                 \
     }                                                                                            \
     _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
-      rb[v] = *reinterpret_cast<const uint4*>(b_src[v] + g * 3 * C + c0);                        \
+      rb[set][v] = *reinterpret_cast<const uint4*>(b_src[v] + g * 3 * C + c0);                   \
     c0 += 64;                                                                                    \
     if (c0 == C) { c0 = 0; ++g; }                                                                \
   }
 
-  int g_cur = 0, c_cur = 0;   // position of the step being computed
-  SLAMHIP_ROW3W_ISSUE();
-  for (int s = 0; s < ksteps; ++s) {
-    __syncthreads();   // the previous step's fragments have been read
-    {
-      uint4* dst = reinterpret_cast<uint4*>(&As[tid * LDS_PITCH]);
-#pragma unroll
-      for (int v = 0; v < 8; ++v) dst[v] = and4(ra[v], b_keep);
-      if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah;
-    }
-#pragma unroll
-    for (int v = 0; v < NBV; ++v) *reinterpret_cast<uint4*>(&Bs[b_dst[v]]) = and4(rb[v], b_keep);
-    __syncthreads();
-    if (s + 1 < ksteps) SLAMHIP_ROW3W_ISSUE();   // in flight while the matrix cores work
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int t = flip ? 8 - (g_cur * 3 + e) : g_cur * 3 + e;     // geometric tap of weight slot (g_cur, e)
-      const int shift = flip ? 2 - e : e;                           // staged row = pixel row + 1 + dx
-      uint32_t keep[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) keep[i] = ((fm[i] >> t) & 1u) ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int kk = 0; kk < 64; kk += 16) {
-        bf16x8 af[2], bfr[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(
-              &As[(wm * 64 + i * 32 + (lane & 31) + shift) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-          af[i] = __builtin_bit_cast(bf16x8, and4(raw, keep[i]));
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8*>(
-              &Bs[(e * BN + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    c_cur += 64;
-    if (c_cur == C) { c_cur = 0; ++g_cur; }
+  // one K-step from register set `set`; `more`: a step two ahead exists and is requested
+#define SLAMHIP_ROW3W_STEP(set, more)                                                            \
+  {                                                                                              \
+    __syncthreads();   /* the previous step's fragments have been read */                        \
+    {                                                                                            \
+      uint4* dst = reinterpret_cast<uint4*>(&As[tid * LDS_PITCH]);                               \
+      _Pragma("unroll") for (int v = 0; v < 8; ++v) dst[v] = and4(ra[set][v], b_keep);           \
+      if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah[set];  \
+    }                                                                                            \
+    _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
+      *reinterpret_cast<uint4*>(&Bs[b_dst[v]]) = and4(rb[set][v], b_keep);                       \
+    __syncthreads();                                                                             \
+    if (more) SLAMHIP_ROW3W_ISSUE(set);   /* in flight while the matrix cores work */            \
+    _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                              \
+      const int t = flip ? 8 - (g_cur * 3 + e) : g_cur * 3 + e;   /* geometric tap of weight slot (g_cur, e) */ \
+      const int shift = flip ? 2 - e : e;                         /* staged row = pixel row + 1 + dx */ \
+      uint32_t keep[2];                                                                          \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i) keep[i] = ((fm[i] >> t) & 1u) ? 0xffffffffu : 0u; \
+      _Pragma("unroll") for (int kk = 0; kk < 64; kk += 16) {                                    \
+        bf16x8 af[2], bfr[2];                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
+          const uint4 raw = *reinterpret_cast<const uint4*>(                                     \
+              &As[(wm * 64 + i * 32 + (lane & 31) + shift) * LDS_PITCH + kk + 8 * (lane >> 5)]); \
+          af[i] = __builtin_bit_cast(bf16x8, and4(raw, keep[i]));                                \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
+          bfr[j] = *reinterpret_cast<const bf16x8*>(                                             \
+              &Bs[(e * BN + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);          \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
+          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
+      }                                                                                          \
+    }                                                                                            \
+    c_cur += 64;                                                                                 \
+    if (c_cur == C) { c_cur = 0; ++g_cur; }                                                      \
   }
+
+  int g_cur = 0, c_cur = 0;   // position of the step being computed
+  SLAMHIP_ROW3W_ISSUE(0);
+  if (ksteps > 1) SLAMHIP_ROW3W_ISSUE(1);
+  for (int s = 0; s < ksteps; s += 2) {
+    SLAMHIP_ROW3W_STEP(0, s + 2 < ksteps);
+    if (s + 1 < ksteps) SLAMHIP_ROW3W_STEP(1, s + 3 < ksteps);
+  }
+#undef SLAMHIP_ROW3W_STEP
 #undef SLAMHIP_ROW3W_ISSUE
 
+  // the 256 x 64 output tile leaves through LDS (the A tile's space): rows of 128 bytes, written
+  // to memory as 16-byte chunks, eight lanes per row
+  __syncthreads();   // the last step's fragments have been read
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int n = n0 + j * 32 + (lane & 31);
-        if (m < M && n < N) out_bf16[(long long)m * N + n] = (bf16)acc[i][j][r];
-      }
+      for (int r = 0; r < 16; ++r)
+        As[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_PITCH + j * 32 + (lane & 31)] =
+            (bf16)acc[i][j][r];
+  __syncthreads();
+#pragma unroll
+  for (int v = 0; v < 8; ++v) {
+    const int id = tid + 256 * v, row = id >> 3, c8 = id & 7;
+    if (m0 + row < M)
+      *reinterpret_cast<uint4*>(out_bf16 + (long long)(m0 + row) * N + n0 + c8 * 8) =
+          *reinterpret_cast<const uint4*>(&As[row * LDS_PITCH + c8 * 8]);
+  }
   // records are counted in 64-row groups, two per 128 pixel rows; a wave wholly beyond the last
   // 128-row tile holds zeros and leaves no record
   if (stat_part && m0 / 64 + wm < (M + 127) / 128 * 2) {
