@@ -58,8 +58,9 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
   constexpr int BM = 128;
   constexpr int NT = BN / 64;                 // 32-wide MFMA tiles per wave along n
   constexpr int NB = BN / 32;                 // B loader passes: 8 threads (16 B each) cover one 64-element row
-  __shared__ __attribute__((aligned(16))) bf16 As[BM * LDS_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[BN * LDS_PITCH];
+  __shared__ __attribute__((aligned(16))) bf16 smem[(BM + BN) * LDS_PITCH];   // A tile, B tile; the output tile at the end
+  bf16* const As = smem;
+  bf16* const Bs = smem + BM * LDS_PITCH;
 
   // Workgroups are dealt round-robin to the 8 XCDs; give each XCD one contiguous run of
   // tiles so the n-tiles of a pixel tile and its neighbours (tap halos) share an L2.
@@ -164,8 +165,32 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 #undef SLAMHIP_IGEMM_ISSUE
 
   // C/D layout of the 32x32 tile: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+  // A bfloat16-only output tile that lies wholly inside N leaves through LDS: rows of BN
+  // elements written to memory as 16-byte chunks (BN / 8 lanes per row) instead of 64-byte runs
+  // of 2-byte stores.
+  const bool staged = WRITE_BF16 && !WRITE_F32 && n0 + BN <= N && (N & 7) == 0;
+  if (staged) {
+    constexpr int OP = BN + 8;                // pitch of the staged tile
+    __syncthreads();   // the last step's fragments have been read
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          smem[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * OP + wn * (BN / 2) + j * 32 + (lane & 31)] =
+              (bf16)acc[i][j][r];
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < BN / 16; ++v) {
+      const int id = tid + 256 * v, row = id / (BN / 8), c8 = id % (BN / 8);
+      if (m0 + row < M)
+        *reinterpret_cast<uint4*>(out_bf16 + (long long)(m0 + row) * N + n0 + c8 * 8) =
+            *reinterpret_cast<const uint4*>(&smem[row * OP + c8 * 8]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2 && !staged; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
