@@ -416,8 +416,10 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int Ktot = 9 * C;
 
-  // A loader: thread -> staged row tid (pixel m0 - 1 + row), all 128 bytes of the 64 channels;
-  // threads 0..15 also fetch one 16-byte chunk of the two extra rows 256, 257
+  // A loader: eight passes; in pass v thread -> staged row (tid >> 3) + 32 v (pixel m0 - 1 + row),
+  // 16-byte chunk tid & 7, so that eight lanes read one row's 128 bytes and a wave-instruction
+  // touches 8 lines instead of 64; threads 0..15 also fetch one chunk of the two extra rows 256, 257
+  const int a_row = tid >> 3, a_chunk = tid & 7;
   const int h_row = BM + (tid >> 3), h_chunk = tid & 7;
   const bool has_halo = tid < 16;
   const bf16* b_src[NBV];
@@ -464,10 +466,11 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
 #define SLAMHIP_ROW3W_ISSUE(set)                                                                 \
   {                                                                                              \
     const int dy = (flip ? 2 - g : g) - 1;                                                       \
-    long long q = (long long)m0 - 1 + tid + (long long)dy * W;                                   \
-    q = q < 0 ? 0 : (q > M - 1 ? M - 1 : q);                                                     \
-    const uint4* src = reinterpret_cast<const uint4*>(A + q * C + c0);                           \
-    _Pragma("unroll") for (int v = 0; v < 8; ++v) ra[set][v] = src[v];                           \
+    _Pragma("unroll") for (int v = 0; v < 8; ++v) {                                              \
+      long long q = (long long)m0 - 1 + a_row + 32 * v + (long long)dy * W;                      \
+      q = q < 0 ? 0 : (q > M - 1 ? M - 1 : q);                                                   \
+      ra[set][v] = *reinterpret_cast<const uint4*>(A + q * C + c0 + a_chunk * 8);                \
+    }                                                                                            \
     if (has_halo) {                                                                              \
       long long qh = (long long)m0 - 1 + h_row + (long long)dy * W;                              \
       qh = qh < 0 ? 0 : (qh > M - 1 ? M - 1 : qh);                                               \
@@ -484,8 +487,8 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
   {                                                                                              \
     __syncthreads();   /* the previous step's fragments have been read */                        \
     {                                                                                            \
-      uint4* dst = reinterpret_cast<uint4*>(&As[tid * LDS_PITCH]);                               \
-      _Pragma("unroll") for (int v = 0; v < 8; ++v) dst[v] = and4(ra[set][v], b_keep);           \
+      _Pragma("unroll") for (int v = 0; v < 8; ++v)                                              \
+        *reinterpret_cast<uint4*>(&As[(a_row + 32 * v) * LDS_PITCH + a_chunk * 8]) = and4(ra[set][v], b_keep); \
       if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah[set];  \
     }                                                                                            \
     _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
