@@ -64,6 +64,13 @@ def test_version_and_error_text():
     assert rc == -1
     rc = lib.slamhip_wgrad_bf16(ctypes.c_void_p(8), ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 4, 4, 48, 64, 9, None)
     assert rc == -3       # channels not a multiple of 64
+    # the optimizer's shadow copy may not be longer than the parameters; null operands are errors
+    p8 = ctypes.c_void_p(8)
+    rc = lib.slamhip_adam_step_shadow(p8, p8, p8, p8, 10, 0.01, 0.9, 0.999, 1e-8, 1, 1.0, p8, 11, None)
+    assert rc == -1 and b"shadow" in lib.slamhip_last_error()
+    rc = lib.slamhip_adam_step_shadow(None, p8, p8, p8, 10, 0.01, 0.9, 0.999, 1e-8, 1, 1.0, None, 0, None)
+    assert rc == -1
+    assert lib.slamhip_transpose_bf16(None, p8, 8, 8, None) == -1
     assert lib.slamhip_pair_loss_workspace_bytes(64, 1) == 64 * 64
     assert lib.slamhip_pair_loss_workspace_bytes(3, 4) == 3 * 4 * 64
 
