@@ -2154,10 +2154,11 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
   // 256 x 64 tiles another 4-5 % at 224 x 224 and nothing at 112 x 112)
   // (128-wide outputs too, as two 64-wide tiles: 405 -> 387 us at 112 x 112 x 64 -> 128, 569 -> 554 us
   // forward and 567 -> 547 us data gradient at 112 x 112 x 128 -> 128; SLAMHIP_IGEMM_ROW3_N128: 0 off,
-  // 1 from 64 channels only, 2 from 64 and 128 channels)
-  static const int row3_n128 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3_N128"); return e ? atoi(e) : 2; }();
-  const bool row3_shape = N % 64 == 0 && (N % 128 != 0 || (row3_n128 && row3 == 2 && N == 128 && (C == 64 || (row3_n128 == 2 && C == 128))));
-  if (row3 && out_bf16 && !out_f32 && row3_shape && C <= 128 && M >= 128 * 1024) {
+  // 1 from 64 channels only, 2 from 64 and 128 channels, 3 from 256 channels as well: 306 -> 275 us
+  // data gradient at 56 x 56 x 256 -> 128)
+  static const int row3_n128 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3_N128"); return e ? atoi(e) : 3; }();
+  const bool row3_shape = N % 64 == 0 && (N % 128 != 0 || (row3_n128 && row3 == 2 && N == 128 && (C == 64 || (row3_n128 >= 2 && C == 128) || (row3_n128 >= 3 && C == 256))));
+  if (row3 && out_bf16 && !out_f32 && row3_shape && C <= (row3_n128 >= 3 ? 256 : 128) && M >= 128 * 1024) {
     if (row3 == 2) {   // 256 x 64 tiles, 64 x 64 per wave
       const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 64, total = m_tiles * n_tiles;
       hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,

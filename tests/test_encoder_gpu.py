@@ -388,7 +388,8 @@ def test_fused_bn_relu_pool_matches_the_separate_kernels(B, H, W, C):
 
 @pytest.mark.parametrize("B,H,W,C,N", [(3, 224, 224, 64, 64), (2, 260, 256, 128, 64), (11, 112, 112, 128, 64),
                                        (3, 211, 208, 64, 64),   # pixels not a multiple of the 256-row tile
-                                       (11, 112, 112, 64, 128), (11, 112, 112, 128, 128)])   # two 64-wide tiles
+                                       (11, 112, 112, 64, 128), (11, 112, 112, 128, 128),   # two 64-wide tiles
+                                       (42, 56, 56, 256, 128)])
 def test_filter_row_convolution_kernel(ops, B, H, W, C, N):
     """Layers with many pixels (>= 128 Ki), at most 128 channels per tap and 64 outputs take the filter-row
     kernel (one K-step per filter row, taps read the staged tile at row offsets, validity as
