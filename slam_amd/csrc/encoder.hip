@@ -402,7 +402,7 @@ igemm_row3_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, 
 __global__ void __launch_bounds__(256, 2)
 igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
                         int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
-                        float* __restrict__ stat_part) {
+                        float* __restrict__ stat_part, int m_tile0) {
   constexpr int BM = 256, BN = 64, AR = BM + 2;
   constexpr int NBV = 3 * BN / 32;            // 16-byte B loads per thread and step
   __shared__ __attribute__((aligned(16))) bf16 As[AR * LDS_PITCH];
@@ -411,7 +411,7 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
   const int per_xcd = (total_tiles + 7) >> 3;
   const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (work >= total_tiles) return;
-  const int m0 = (work / n_tiles) * BM, n0 = (work % n_tiles) * BN;
+  const int m0 = (m_tile0 + work / n_tiles) * BM, n0 = (work % n_tiles) * BN;   // m_tile0: first pixel tile of this launch
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
   const int Ktot = 9 * C;
@@ -2139,9 +2139,18 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
     launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, flip, s, stat_part, 0, m_big);
     long long records = 2LL * m_big;
     if (m_big < m_tiles) {
+      // the leftover pixel rows: filter-row kernel (a third of the K-steps, two in flight), which a
+      // launch of a few dozen workgroups, bound by the latency of its K-steps, finishes sooner
+      static const int leftover = [] { const char* e = getenv("SLAMHIP_IGEMM256_LEFTOVER"); return e ? atoi(e) : 1; }();
       const int m_small = (int)((M - 256LL * m_big + 127) / 128);
-      launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, flip, s,
-                           stat_part ? stat_part + records * 2 * N : nullptr, 1, 2 * m_big, m_small);
+      float* part = stat_part ? stat_part + records * 2 * N : nullptr;
+      if (leftover == 1) {
+        const int m_rest = (m_small + 1) / 2, nt = N / 64, total_rest = m_rest * nt;
+        hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total_rest + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
+                           (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, nt, total_rest, part, m_big);
+      } else {
+        launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, flip, s, part, 1, 2 * m_big, m_small);
+      }
       records += 2LL * m_small;
     }
     return records;
@@ -2162,7 +2171,7 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
     if (row3 == 2) {   // 256 x 64 tiles, 64 x 64 per wave
       const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 64, total = m_tiles * n_tiles;
       hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
-                         (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part);
+                         (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, 0);
       return (M + 127) / 128 * 2;
     }
     const int m_tiles = (int)((M + 127) / 128), n_tiles = N / 64, total = m_tiles * n_tiles;
