@@ -211,7 +211,8 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
 
 /* The two calls above fused with the 2x2 stride-2 max-pool that follows the last
  * layer of every block (cnn_model.py:40,45,50,56,62).  Forward: z [B,H,W,C] -> y (same
- * shape) and pooled [B,H/2,W/2,C] in one pass.  Backward: dpooled [B,H/2,W/2,C] is
+ * shape; NULL = not written, nothing downstream of a pooled layer reads it) and
+ * pooled [B,H/2,W/2,C] in one pass.  Backward: dpooled [B,H/2,W/2,C] is
  * the gradient at the pooled tensor; it goes to each window's first maximum of y
  * (recomputed from z), through the ReLU gate and the batch-norm backward into dz
  * [B,H,W,C]; red2c as above.  H and W even. */

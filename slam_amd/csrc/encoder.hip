@@ -1778,7 +1778,7 @@ bn_relu_pool_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ su
         o[j] = (bf16)fmaxf(__builtin_fmaf((float)v[q][j] - mean[j], r[j], bet[j]), 0.0f);
         best[j] = (q == 0 || (float)o[j] > (float)best[j]) ? o[j] : best[j];
       }
-      reinterpret_cast<bf16x8*>(y)[w.o[q]] = o;
+      if (y) reinterpret_cast<bf16x8*>(y)[w.o[q]] = o;   // optional: nothing downstream of a pooled layer reads it
     }
     reinterpret_cast<bf16x8*>(pooled)[i] = best;
   }
@@ -2469,7 +2469,7 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
 
 int slamhip_bn_relu_pool_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta, void* y,
                              void* pooled, int B, int H, int W, int C, float eps, void* stream) {
-  SLAMHIP_REQUIRE(z && sums2c && gamma && beta && y && pooled && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 &&
+  SLAMHIP_REQUIRE(z && sums2c && gamma && beta && pooled && B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 &&
                       C > 0 && C % 8 == 0,
                   SLAMHIP_E_ARG, "bn_relu_pool_fwd: bad argument (even height and width, channels % 8 == 0)");
   const long long P = (long long)B * H * W, total8 = P / 4 * (C / 8);

@@ -16,6 +16,7 @@ statistics -> ReLU, 2x2 max-pool after every block, two ReLU fully connected
 layers and a linear output layer of `output_dim`.
 """
 import math
+import os
 
 import torch
 
@@ -222,6 +223,8 @@ class VGG16Model:
         self.network_output = torch.empty(B, self.output_dim, **f32)
         self._scratch = {}
         self.trace = None      # set to a dict to keep per-layer gradient copies (tests, debugging)
+        # True (or SLAM_KEEP_FULL_Y=1): pooled batch-norm layers also write their full-resolution output
+        self.keep_full_y = os.environ.get("SLAM_KEEP_FULL_Y", "0") not in ("", "0")
         self._built = True
         return self.network_output
 
@@ -304,7 +307,10 @@ class VGG16Model:
                     ops.conv3x3_stats(h, self._w_fwd[n], a["z"], a["sums"], self._stats_ws)
                 bn = self.params[n + "/bn"]
                 if a["pool"]:       # normalisation, ReLU and the block's max-pool in one pass
-                    ops.bn_relu_pool(a["z"], a["sums"], bn[1], bn[0], a["y"], a["pooled"], self.epsilon)
+                    # the full-resolution y of a pooled layer has no reader (the next layer takes the
+                    # pooled tensor, the backward pass recomputes the gate from z): written on request only
+                    ops.bn_relu_pool(a["z"], a["sums"], bn[1], bn[0], a["y"] if self.keep_full_y else None,
+                                     a["pooled"], self.epsilon)
                     h = a["pooled"]
                     continue
                 ops.bn_relu(a["z"], a["sums"], bn[1], bn[0], a["y"], self.epsilon)

@@ -121,10 +121,12 @@ def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps):
 
 
 def bn_relu_pool(z, sums2c, gamma, beta, y, pooled, eps):
-    """bn_relu and the 2x2 max-pool after it in one pass: y (like z) and pooled [B,H/2,W/2,C]."""
+    """bn_relu and the 2x2 max-pool after it in one pass: y (like z; None = not written) and
+    pooled [B,H/2,W/2,C]."""
     B, H, W, C = _chk(z, BF16, "z").shape
     assert H % 2 == 0 and W % 2 == 0 and C % 8 == 0
-    assert _chk(y, BF16, "y").shape == z.shape and _chk(pooled, BF16, "pooled").shape == (B, H // 2, W // 2, C)
+    assert y is None or _chk(y, BF16, "y").shape == z.shape
+    assert _chk(pooled, BF16, "pooled").shape == (B, H // 2, W // 2, C)
     assert _chk(sums2c, F32, "sums").shape == (2, C)
     assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
     _call("slamhip_bn_relu_pool_fwd", capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y),

@@ -374,6 +374,9 @@ def test_fused_bn_relu_pool_matches_the_separate_kernels(B, H, W, C):
     ops.maxpool2(y_ref, pooled_ref)
     ops.bn_relu_pool(z, sums, gamma, beta, y, pooled, 1e-3)
     assert torch.equal(y, y_ref) and torch.equal(pooled, pooled_ref)
+    pooled_only = torch.empty_like(pooled_ref)
+    ops.bn_relu_pool(z, sums, gamma, beta, None, pooled_only, 1e-3)     # y is optional
+    assert torch.equal(pooled_only, pooled_ref)
     dp = torch.randn(B, H // 2, W // 2, C, generator=g).to(dev).to(torch.bfloat16)
     dy = torch.empty_like(z)
     ops.maxpool2_bwd(y_ref, pooled_ref, dp, dy)
