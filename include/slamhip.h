@@ -209,6 +209,15 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
                         const float* beta, float* red2c, void* dz, long long P, int C, float eps,
                         void* stream);
 
+/* Backward of the first layer (4 input channels, 64 filters, batch-norm, no pool;
+ * cnn_model.py:37,104-113) in two passes: red2c as slamhip_bn_relu_bwd, then the filter
+ * gradient dw [3,3,4,64] of slamhip_conv3x3_small_wgrad with dz computed on the way from dy
+ * (gradient at the layer's output) and z, so that dz is neither written nor read.  Same
+ * arithmetic and the same bfloat16 rounding of dz as the two separate calls. */
+int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* sums2c, const float* gamma,
+                                    const float* beta, float* red2c, const void* x, float* dw, int B, int H,
+                                    int W, float eps, void* stream);
+
 /* The two calls above fused with the 2x2 stride-2 max-pool that follows the last
  * layer of every block (cnn_model.py:40,45,50,56,62).  Forward: z [B,H,W,C] -> y (same
  * shape; NULL = not written, nothing downstream of a pooled layer reads it) and

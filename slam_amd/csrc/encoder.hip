@@ -1373,9 +1373,17 @@ conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ 
 }
 
 // filter gradient: dW[k][n] += sum_p A[p][k] dY[p][n] over a slice of the pixels
+// FUSE_BN: dY is not read; it is computed on the way into LDS from the gradient g at the
+// layer's output and z, i.e. ReLU gate and batch-norm backward of bn_relu_bwd_apply_kernel with
+// the same operations and the same rounding to bfloat16, so that dz of the first layer is
+// neither written nor read (its only reader is this kernel).
+template <bool FUSE_BN>
 __global__ void __launch_bounds__(256)
 conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P,
-                            int H, int W, int px_per_block) {
+                            int H, int W, int px_per_block, const bf16* __restrict__ Z,
+                            const float* __restrict__ sums, const float* __restrict__ red,
+                            const float* __restrict__ gamma, const float* __restrict__ beta, float inv_count,
+                            float eps) {
   constexpr int PX = 64 + 32;   // conflict-free pitch of the transposing reads (see wgrad_bf16_kernel)
   __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];
   __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PX];
@@ -1391,8 +1399,23 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
   uint2 xv[3];
-  uint4 yv[2];
+  uint4 yv[2], zv[2];
   uint32_t keep_x[3], keep_y = 0u;
+  // FUSE_BN: coefficients of this thread's 16 channels (l_q * 16 ...), as in bn_relu_bwd_apply_kernel
+  float mean[16], rr[16], bet[16], k1[16], k2[16];
+  if (FUSE_BN) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int c = l_q * 16 + j;
+      mean[j] = sums[c] * inv_count;
+      const float var = fmaxf(sums[64 + c] * inv_count - mean[j] * mean[j], 0.0f);
+      const float rstd = rsqrtf(var + eps);
+      rr[j] = gamma[c] * rstd;
+      bet[j] = beta[c];
+      k1[j] = red[c] * inv_count;
+      k2[j] = rstd * (red[64 + c] * inv_count);
+    }
+  }
 
 #define SLAMHIP_C4_ISSUE(p0)                                                                    \
   {                                                                                             \
@@ -1409,6 +1432,10 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
     }                                                                                           \
     const uint4* ys = reinterpret_cast<const uint4*>(dY + (long long)pc * 64 + l_q * 16);       \
     yv[0] = ys[0]; yv[1] = ys[1];                                                               \
+    if (FUSE_BN) {                                                                              \
+      const uint4* zs = reinterpret_cast<const uint4*>(Z + (long long)pc * 64 + l_q * 16);      \
+      zv[0] = zs[0]; zv[1] = zs[1];                                                             \
+    }                                                                                           \
     keep_y = in_slice ? 0xffffffffu : 0u;                                                       \
   }
 
@@ -1426,7 +1453,23 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
         for (int i = 9; i < 16; ++i) xd[i] = make_uint2(0u, 0u);
       }
       uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * PX + l_q * 16]);
-      yd[0] = and4(yv[0], keep_y); yd[1] = and4(yv[1], keep_y);
+      if (FUSE_BN) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const bf16x8 vg = __builtin_bit_cast(bf16x8, yv[h]), vz = __builtin_bit_cast(bf16x8, zv[h]);
+          bf16x8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int c = h * 8 + j;
+            const float d = (float)vz[j] - mean[c];
+            const float g = (__builtin_fmaf(d, rr[c], bet[c]) > 0.0f) ? (float)vg[j] : 0.0f;   // forward's y > 0
+            o[j] = (bf16)(rr[c] * ((g - k1[c]) - d * k2[c]));
+          }
+          yd[h] = and4(__builtin_bit_cast(uint4, o), keep_y);
+        }
+      } else {
+        yd[0] = and4(yv[0], keep_y); yd[1] = and4(yv[1], keep_y);
+      }
     }
     __syncthreads();
     if (p0 + 64 < p_end) SLAMHIP_C4_ISSUE(p0 + 64);
@@ -2415,8 +2458,10 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
   if (Cin == 4 && Cout == 64) {
     // about 2048 workgroups, slices in multiples of 64 pixels
     int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
-    hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0, s,
-                       (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block);
+    hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<false>, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0,
+                       s, (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block, (const bf16*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                       0.0f, 0.0f);
   } else {
     hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x,
                        (const bf16*)dy, dw, P, H, W, Cin, Cout);
@@ -2463,6 +2508,27 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* sums2c, const float* gamma,
+                                    const float* beta, float* red2c, const void* x, float* dw, int B, int H, int W,
+                                    float eps, void* stream) {
+  SLAMHIP_REQUIRE(dy && z && sums2c && gamma && beta && red2c && x && dw && B > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
+                  "bn_relu_bwd_first_layer: bad argument");
+  const long long Pl = (long long)B * H * W;
+  SLAMHIP_REQUIRE(Pl <= 0x7fffffffLL / 64, SLAMHIP_E_SIZE, "bn_relu_bwd_first_layer: too many pixels");
+  const int P = (int)Pl, C = 64;
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * 4 * (size_t)C, s));
+  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
+                     (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, P, C, 1.0f / (float)P, eps);
+  const int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
+  hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<true>, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0, s,
+                     (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block, (const bf16*)z, sums2c,
+                     (const float*)red2c, gamma, beta, 1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -223,6 +223,8 @@ class VGG16Model:
         self.network_output = torch.empty(B, self.output_dim, **f32)
         self._scratch = {}
         self.trace = None      # set to a dict to keep per-layer gradient copies (tests, debugging)
+        # SLAM_FUSE_FIRST_BWD=0: the first layer's backward as two separate calls through dz
+        self.fuse_first_backward = os.environ.get("SLAM_FUSE_FIRST_BWD", "1") not in ("", "0")
         # True (or SLAM_KEEP_FULL_Y=1): pooled batch-norm layers also write their full-resolution output
         self.keep_full_y = os.environ.get("SLAM_KEEP_FULL_Y", "0") not in ("", "0")
         self._built = True
@@ -403,6 +405,13 @@ class VGG16Model:
             n = a["name"]
             g_out = g.clone() if self.trace is not None else None
             dz = self._buf(("dz", a["z"].shape), a["z"])
+            if (i == 0 and self.fuse_first_backward and self.batch_norm and not a["pool"] and self.trace is None
+                    and a["z"].shape[-1] == 64 and self._x.shape[-1] == 4):
+                # first layer: its dz has one reader, the filter gradient, which computes it on the way
+                bn = self.params[n + "/bn"]
+                ops.bn_relu_bwd_first_layer(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], self._x,
+                                            self.grads[n + "/weights"], self.epsilon)
+                continue
             if self.batch_norm:
                 bn = self.params[n + "/bn"]
                 if a["pool"]:   # pool backward + ReLU gate + batch-norm backward, no upsampled gradient tensor

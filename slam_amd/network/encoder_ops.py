@@ -120,6 +120,18 @@ def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps):
           capi.ptr(red2c), capi.ptr(dz), P, C, float(eps))
 
 
+def bn_relu_bwd_first_layer(dy, z, sums2c, gamma, beta, red2c, x, dw, eps):
+    """bn_relu_bwd and conv3x3_small_wgrad of the first layer (4 -> 64 channels) without the
+    dz tensor in between: red2c [2,64] and dw [3,3,4,64] come out."""
+    B, H, W, C = _chk(z, BF16, "z").shape
+    assert C == 64 and _chk(dy, BF16, "dy").shape == z.shape and _chk(x, BF16, "x").shape == (B, H, W, 4)
+    assert _chk(sums2c, F32, "sums").shape == (2, C) and _chk(red2c, F32, "red").shape == (2, C)
+    assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
+    assert _chk(dw, F32, "dw").shape == (3, 3, 4, C)
+    _call("slamhip_bn_relu_bwd_first_layer", capi.ptr(dy), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma),
+          capi.ptr(beta), capi.ptr(red2c), capi.ptr(x), capi.ptr(dw), B, H, W, float(eps))
+
+
 def bn_relu_pool(z, sums2c, gamma, beta, y, pooled, eps):
     """bn_relu and the 2x2 max-pool after it in one pass: y (like z; None = not written) and
     pooled [B,H/2,W/2,C]."""

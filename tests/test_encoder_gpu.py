@@ -452,3 +452,29 @@ def test_adam_shadow_matches_plain_update(ops):
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
     assert torch.equal(shadow[:ns].cpu(), pb[:ns].to(torch.bfloat16).cpu())
     assert bool((shadow[ns:] == 7.0).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 10, 12), (3, 32, 32), (1, 7, 9)])
+def test_first_layer_backward_fused(ops, B, H, W):
+    """Batch-norm backward + filter gradient of the first layer without the dz tensor against
+    the two separate calls (same arithmetic; the filter gradient differs only by the order of
+    its float atomics)."""
+    g = torch.Generator().manual_seed(B * 100 + H)
+    dev = "cuda"
+    x = torch.randn(B, H, W, 4, generator=g).to(dev).to(torch.bfloat16)
+    z = torch.randn(B, H, W, 64, generator=g).to(dev).to(torch.bfloat16)
+    dy = torch.randn(B, H, W, 64, generator=g).to(dev).to(torch.bfloat16)
+    gamma = (1.0 + 0.1 * torch.randn(64, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(64, generator=g)).to(dev)
+    sums = torch.empty(2, 64, device=dev)
+    ops.channel_stats(z, sums)
+    red_ref, red = torch.empty(2, 64, device=dev), torch.full((2, 64), 7.0, device=dev)
+    dz = torch.empty_like(z)
+    dw_ref, dw = torch.empty(3, 3, 4, 64, device=dev), torch.full((3, 3, 4, 64), 7.0, device=dev)
+    ops.bn_relu_bwd(dy, z, sums, gamma, beta, red_ref, dz, 1e-3)
+    ops.conv3x3_small_wgrad(x, dz, dw_ref)
+    ops.bn_relu_bwd_first_layer(dy, z, sums, gamma, beta, red, x, dw, 1e-3)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(dw.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max()))
