@@ -132,6 +132,14 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
                             uint32_t* counts, void* workspace, size_t workspace_bytes,
                             void* stream);
 
+/* Zero-fills a workspace of slamhip_pair_loss_fused on `stream`.  A call that was
+ * interrupted (a failed launch, a device error, a process that reuses the buffer for
+ * another shape after one) may leave accumulators or tickets set, and every later call
+ * on that workspace would then return wrong sums without an error: callers run this
+ * after any failure before they use the workspace again.  No counterpart in the
+ * reference (the workspace is this library's own). */
+int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, void* stream);
+
 /* Same arithmetic as slamhip_pair_loss_fused, per-pixel results written out
  * (each output may be NULL): warped_rgb float32 [B,k,H,W,3], warped_depth
  * float32 [B,k,H,W], r_photo float32 [B,k,H,W,3], r_geo float32 [B,k,H,W],

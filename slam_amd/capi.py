@@ -41,6 +41,7 @@ SIGNATURES = {
     "slamhip_pair_loss_fused": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                  _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                  ctypes.c_size_t, _c_void_p], _c_int),
+    "slamhip_pair_loss_reset_workspace": ([_c_void_p, ctypes.c_size_t, _c_void_p], _c_int),
     "slamhip_warp_materialize": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                   _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                   _c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p], _c_int),

@@ -983,27 +983,21 @@ size_t slamhip_pair_loss_workspace_bytes(int B, int k) {
   return sizeof(PairAcc) * (size_t)B * (size_t)k;
 }
 
-int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
-                            const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
-                            int B, int k, int H, int W, double* sums, uint32_t* counts, void* workspace,
-                            size_t workspace_bytes, void* stream) {
-  SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
-                  "pair_loss_fused: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
-  if (B == 0) return SLAMHIP_OK;  // an empty batch has no buffers to check
+// Argument checks and launch shared by the two fused entry points; `workspace` holds at least
+// B * k zero-filled PairAcc records.
+static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                            const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor, int B,
+                            int k, int H, int W, double* sums, uint32_t* counts, void* workspace, hipStream_t s) {
   SLAMHIP_REQUIRE(depth1 && rgb1 && depth2 && rgb2 && rel4x4 && K && sums && counts && workspace, SLAMHIP_E_ARG,
-                  "pair_loss_fused: null pointer");
+                  "%s: null pointer", who);
   SLAMHIP_REQUIRE(H <= 32767 && W <= 65535 && (long long)H * W <= 0x20000000LL, SLAMHIP_E_SIZE,
-                  "pair_loss_fused: image larger than 65535 x 32767 or 2^29 pixels");
-  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_pair_loss_workspace_bytes(B, k), SLAMHIP_E_SIZE,
-                  "pair_loss_fused: workspace of %zu bytes, need %zu", workspace_bytes,
-                  slamhip_pair_loss_workspace_bytes(B, k));
+                  "%s: image larger than 65535 x 32767 or 2^29 pixels", who);
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4), SLAMHIP_E_ARG,
-                  "pair_loss_fused: misaligned workspace or output");
-  hipStream_t s = (hipStream_t)stream;
+                  "%s: misaligned workspace or output", who);
   const int tiles_x = (W + TILE_W - 1) / TILE_W, tiles_y = (H + TILE_H - 1) / TILE_H;
   const long long groups = ((long long)B + 7) / 8;
   const long long nblocks = groups * 8 * tiles_x * tiles_y;
-  SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "pair_loss_fused: grid too large");
+  SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "%s: grid too large", who);
   const Cam cam{K[0], K[1], K[2], K[3], factor};
   // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
   const int stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
@@ -1023,6 +1017,28 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
   else SLAMHIP_LAUNCH_FUSED(false, false);
 #undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                            const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
+                            int B, int k, int H, int W, double* sums, uint32_t* counts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
+                  "pair_loss_fused: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
+  if (B == 0) return SLAMHIP_OK;  // an empty batch has no buffers to check
+  SLAMHIP_REQUIRE(workspace != nullptr, SLAMHIP_E_ARG, "pair_loss_fused: null pointer");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_pair_loss_workspace_bytes(B, k), SLAMHIP_E_SIZE,
+                  "pair_loss_fused: workspace of %zu bytes, need %zu", workspace_bytes,
+                  slamhip_pair_loss_workspace_bytes(B, k));
+  return launch_pair_loss("pair_loss_fused", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W, sums,
+                          counts, workspace, (hipStream_t)stream);
+}
+
+int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(workspace || workspace_bytes == 0, SLAMHIP_E_ARG, "pair_loss_reset_workspace: null workspace");
+  if (workspace_bytes == 0) return SLAMHIP_OK;
+  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream));
   return SLAMHIP_OK;
 }
 

@@ -123,13 +123,21 @@ def _pair_args(depth1, rgb1, depth2, rgb2, rel):
 _workspaces = {}
 
 
+def _reset_workspace(ws, stream):
+    """Zero-fill a workspace on the stream that launches with it."""
+    capi.check(capi.load().slamhip_pair_loss_reset_workspace(ws.data_ptr(), ws.numel(), stream),
+               "slamhip_pair_loss_reset_workspace")
+
+
 def _workspace(device, stream, nbytes):
     """Zero-filled scratch of the fused kernel, one per (device, stream); the
-    kernel hands it back zero-filled, so it is cleared only when (re)allocated."""
+    kernel hands it back zero-filled, so it is cleared only when (re)allocated
+    (on the launching stream) or after a failed call (`pair_loss` drops it)."""
     key = (device.index, stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros((max(nbytes, 1 << 16),), dtype=torch.uint8, device=device)
+        ws = torch.empty((max(nbytes, 1 << 16),), dtype=torch.uint8, device=device)
+        _reset_workspace(ws, stream)
         _workspaces[key] = ws
     return ws
 
@@ -147,10 +155,15 @@ def pair_loss(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR, out=None):
     lib = capi.load()
     stream = capi.current_stream()
     ws = _workspace(d1.device, stream, lib.slamhip_pair_loss_workspace_bytes(B, k))
-    capi.check(lib.slamhip_pair_loss_fused(d1.data_ptr(), c1.data_ptr(), d2.data_ptr(), c2.data_ptr(),
-                                           r.data_ptr(), capi.K4(K), float(factor), B, k, H, W,
-                                           sums.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
-                                           stream), "slamhip_pair_loss_fused")
+    try:
+        capi.check(lib.slamhip_pair_loss_fused(d1.data_ptr(), c1.data_ptr(), d2.data_ptr(), c2.data_ptr(),
+                                               r.data_ptr(), capi.K4(K), float(factor), B, k, H, W,
+                                               sums.data_ptr(), counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               stream), "slamhip_pair_loss_fused")
+    except Exception:
+        # a failed call may leave tickets or partial sums behind: never reuse that buffer as it is
+        _workspaces.pop((d1.device.index, stream), None)
+        raise
     return sums, counts
 
 
@@ -172,7 +185,8 @@ class PairLossPlan(object):
         self.sums = torch.empty((self.B, self.k, capi.NSUMS), dtype=torch.float64, device=dev)
         self.counts = torch.empty((self.B, self.k, capi.NCOUNTS), dtype=torch.int32, device=dev)
         nbytes = self._lib.slamhip_pair_loss_workspace_bytes(self.B, self.k)
-        self._ws = torch.zeros((max(nbytes, 64),), dtype=torch.uint8, device=dev)   # owned by this plan
+        self._ws = torch.empty((max(nbytes, 64),), dtype=torch.uint8, device=dev)   # owned by this plan
+        _reset_workspace(self._ws, self.stream)   # ordered before the launches: same stream
         self._tail = (self.sums.data_ptr(), self.counts.data_ptr(), self._ws.data_ptr(), self._ws.numel(), self.stream)
 
     def rebind(self, depth1, rgb1, depth2, rgb2, rel):
@@ -187,8 +201,16 @@ class PairLossPlan(object):
     def run(self):
         rc = self._fn(*self._head, self.K, self.factor, self.B, self.k, self.H, self.W, *self._tail)
         if rc != 0:
+            try:
+                self.reset()
+            except RuntimeError:
+                pass   # the first failure is the one to report
             capi.check(rc, "slamhip_pair_loss_fused")
         return self.sums, self.counts
+
+    def reset(self):
+        """Zero the plan's workspace on its stream (after a failed or interrupted run)."""
+        _reset_workspace(self._ws, self.stream)
 
 
 def warp(depth1, rgb1, depth2, rgb2, rel, K, factor=FACTOR):

@@ -287,3 +287,22 @@ def test_high_res_four_neighbours(fp):
     s_o, c_o = c_oracle.pair_loss(d1[:1], c1[:1], d2[:1, 2:3], c2[:1, 2:3], rel[:1, 2:3], K, 1.0)
     assert np.array_equal(got_c[0, 2], c_o[0, 0].astype(np.int64))
     np.testing.assert_allclose(sums.cpu().numpy()[0, 2], s_o[0, 0], rtol=RTOL)
+
+
+def test_workspace_recovery(fp):
+    """A workspace left dirty by an interrupted call gives wrong sums silently; the reset
+    entry point (and the plan's reset()) bring it back."""
+    K = fp.intrinsics(1)
+    d1, c1, d2, c2, rel = _pairs(3, 1, 48, 64, seed=9)
+    args = [_dev(a) for a in (d1, c1, d2, c2, rel)]
+    want_s, want_c = fp.pair_loss(*args, K, 1.0)
+    plan = fp.PairLossPlan(*args, K, 1.0)
+    s, c = plan.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(_u32(c), _u32(want_c))
+    plan._ws.fill_(0x5A)            # what an aborted launch may leave: tickets and partial sums
+    plan.reset()
+    s, c = plan.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(_u32(c), _u32(want_c))
+    np.testing.assert_allclose(s.cpu().numpy(), want_s.cpu().numpy(), rtol=1e-12)
