@@ -140,6 +140,22 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
  * reference (the workspace is this library's own). */
 int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, void* stream);
 
+/* slamhip_pair_loss_fused for callers that cannot allocate device memory (code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it has no
+ * counterpart in the reference.  Same inputs, outputs and arithmetic, no workspace
+ * argument: the accumulator records live in a device array built into the library
+ * (SLAMHIP_STATIC_MAX_PAIRS records of 64 bytes on every GPU the library runs on, held
+ * until the process ends), which the call clears on `stream` before the launch.  It
+ * calls no hipMalloc / hipFree.  B * k beyond SLAMHIP_STATIC_MAX_PAIRS is rejected with
+ * SLAMHIP_E_SIZE.  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (different streams or threads) race and must be serialised by the caller.  The first call on
+ * a device looks the array's address up (hipGetSymbolAddress); make that call outside a graph capture. */
+#define SLAMHIP_STATIC_MAX_PAIRS 8192
+int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                                   const uint8_t* rgb2, const double* rel4x4, const double K[4],
+                                   double factor, int B, int k, int H, int W, double* sums,
+                                   uint32_t* counts, void* stream);
+
 /* Same arithmetic as slamhip_pair_loss_fused, per-pixel results written out
  * (each output may be NULL): warped_rgb float32 [B,k,H,W,3], warped_depth
  * float32 [B,k,H,W], r_photo float32 [B,k,H,W,3], r_geo float32 [B,k,H,W],

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("SLAMHIP_LIB") or os.path.join(_HERE, "_lib", "libslam
 
 NSUMS = 4
 NCOUNTS = 4
+STATIC_MAX_PAIRS = 8192
 M_VALID0, M_INB, M_WARP, M_GEO = 1, 2, 4, 8
 
 _c_void_p = ctypes.c_void_p
@@ -41,6 +42,8 @@ SIGNATURES = {
     "slamhip_pair_loss_fused": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                  _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,
                                  ctypes.c_size_t, _c_void_p], _c_int),
+    "slamhip_pair_loss_fused_static": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
+                                        _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p], _c_int),
     "slamhip_pair_loss_reset_workspace": ([_c_void_p, ctypes.c_size_t, _c_void_p], _c_int),
     "slamhip_warp_materialize": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                   _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,

@@ -14,6 +14,7 @@
 // here is GEMM-shaped, so no MFMA.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -1040,6 +1041,40 @@ int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, v
   if (workspace_bytes == 0) return SLAMHIP_OK;
   SLAMHIP_HIP(hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream));
   return SLAMHIP_OK;
+}
+
+// ---- the fused kernel for callers that cannot allocate ---------------------
+// The accumulator records live in a file-scope device array instead of a caller's
+// workspace.  Every GPU holds its own copy of the array at its own address: the
+// address is looked up once per device (with that device current) and only that
+// pointer, never the array's name, is used by host code afterwards.
+static __device__ __align__(256) unsigned char scratch[SLAMHIP_STATIC_MAX_PAIRS * sizeof(PairAcc)];
+constexpr int MAX_DEVICES = 64;
+static std::atomic<void*> scratch_ptr[MAX_DEVICES];
+
+int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                                   const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
+                                   int B, int k, int H, int W, double* sums, uint32_t* counts, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
+                  "pair_loss_fused_static: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE((long long)B * k <= SLAMHIP_STATIC_MAX_PAIRS, SLAMHIP_E_SIZE,
+                  "pair_loss_fused_static: %lld (anchor, neighbour) pairs, the built-in scratch holds %d "
+                  "(use slamhip_pair_loss_fused with a workspace)", (long long)B * k, SLAMHIP_STATIC_MAX_PAIRS);
+  int dev = -1;
+  SLAMHIP_HIP(hipGetDevice(&dev));
+  SLAMHIP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, SLAMHIP_E_SIZE, "pair_loss_fused_static: device %d", dev);
+  void* ptr = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!ptr) {   // first call on this device (racing first calls look up the same address)
+    SLAMHIP_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    SLAMHIP_REQUIRE(ptr != nullptr, SLAMHIP_E_HIP, "pair_loss_fused_static: no address for the scratch array");
+    scratch_ptr[dev].store(ptr, std::memory_order_release);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // the array keeps whatever the last call (possibly an interrupted one) left: clear the records of this call
+  SLAMHIP_HIP(hipMemsetAsync(ptr, 0, sizeof(PairAcc) * (size_t)B * (size_t)k, s));
+  return launch_pair_loss("pair_loss_fused_static", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W,
+                          sums, counts, ptr, s);
 }
 
 int slamhip_warp_materialize(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
