@@ -1,0 +1,796 @@
+// Fused frame-pair kernel for gfx950 (MI355X): back-projection, rigid transform,
+// re-projection, in-image predicates, bilinear warp of the neighbour frame and the
+// residual / mask reductions in one pass over the native uint16 depth / uint8 colour
+// planes, nothing materialised.
+//
+// Arithmetic contract (follows slam/preprocess/test_import.py:148-176): masks, counts
+// and the pixel indices that choose the bilinear taps equal what the reference's
+// float64 operation order gives, bit for bit.  The kernel gets there in two phases:
+//   1  a cheap float64 evaluation of the same projection (per-column / per-row
+//      constants hoisted, one reciprocal per pixel) whose distance from the
+//      reference's value is bounded rigorously; every decision the reference takes
+//      compares a coordinate with an integer (0, W-1, W, H-1, H, or floor), so a
+//      pixel whose cheap coordinates are farther than the bound from every integer
+//      takes the same decisions and is finished in this phase;
+//   2  every other pixel (within the bound of an integer, outside the staged window,
+//      behind the camera, non-finite) is redone in the reference's exact order with
+//      IEEE divisions (geom_device.h), typically a few pixels in 10^5.
+// Colour and depth interpolation runs in float32 (1e-4 relative to the oracle).
+//
+// The kernel is HBM-streaming by its bytes (10 B per pixel pair) but bound by vector
+// instruction issue; nothing here is GEMM-shaped, so no MFMA.  This file is built
+// with -ffp-contract=off: no product/sum pair is fused except where fma() is written.
+#include <atomic>
+
+#include "geom_device.h"
+
+namespace slamhip {
+
+// ---------------------------------------------------------------------------
+// tiling
+// ---------------------------------------------------------------------------
+// One 256-thread workgroup owns a TILE_W x TH tile of anchor pixels.  Wave w owns the
+// 64 columns (w & 1) * 64 .. +63 of rows (w >> 1) * TH/2 .. +TH/2-1: a lane walks down
+// one image column, so the 64 lanes of a wave read 64 adjacent anchor pixels at every
+// step (coalesced) and gather from adjacent LDS cells (no bank conflicts for the smooth
+// flow of small camera motions), and everything that depends on the column alone is a
+// per-lane constant.  Per neighbour frame:
+//   A  wave 0 predicts the window of the neighbour frame the tile's taps fall into
+//      (the tile's corners projected in float32 at the nearest and farthest depth);
+//   B  all waves stage that window into LDS as 8-byte cells {half(1024+R) | half(1024+G),
+//      half(1024+B) | raw depth} with 16-byte / 8-byte global loads;
+//   C  phase 1 and phase 2 above; a tap outside the window (large parallax, a window
+//      cut at WIN_PITCH x WIN_ROWS) is gathered straight from global memory in phase 2,
+//      so the prediction never affects results.
+// Predicates are 64-bit lane masks in scalar registers (one vector compare each,
+// combined and counted on the scalar unit).  Reduction: sums by DPP row reductions,
+// the four waves through LDS, then one float64 / uint32 atomic per quantity per
+// workgroup into the accumulators of the caller's workspace.  The workgroup that draws
+// the last ticket of an (image, neighbour) pair moves the totals to the outputs with
+// atomic exchanges, which also leaves the workspace zeroed for the next call: no memset
+// and no second kernel on the stream.
+constexpr int TILE_W = 128;
+constexpr int TPB = 256;
+constexpr int CHUNK = 8;                        // staging granule in pixels (16 B of depth)
+constexpr int WIN_PITCH = 160;                  // LDS window row pitch in cells (multiple of CHUNK)
+// window rows for a tile of th rows: th + 8, one less where that lets four workgroups share a CU's 160 KiB
+constexpr int win_rows(int th) { return th == 24 ? 31 : th + 8; }
+
+// workspace record of one (image, neighbour) pair: 64 bytes
+struct PairAcc {
+  double sums[SLAMHIP_NSUMS];
+  unsigned int counts[SLAMHIP_NCOUNTS];
+  unsigned int ticket;
+  unsigned int pad[3];
+};
+static_assert(sizeof(PairAcc) == 64, "PairAcc must stay 64 bytes");
+
+struct FusedArgs {
+  const uint16_t* depth1;
+  const uint8_t* rgb1;
+  const uint16_t* depth2;
+  const uint8_t* rgb2;
+  const double* rel;
+  PairAcc* ws;
+  double* sums;
+  unsigned int* counts;
+  Cam cam;
+  // host-rounded quotients used by phase 1 only (any rounding is covered by the bound)
+  double fx_fy, fy_fx, inv_fac, inv_fx_fac, inv_fy_fac;
+  float axm, aym;      // max |col - cx| / fx and max |row - cy| / fy over the image
+  float extent;        // W + H + |cx| + |cy| + 8: bound of |u - cx|, |v - cy| for pixels near the image
+  int B, k, H, W, tiles_x, tiles_y;
+  int stage_vec;       // the window can be staged with 16-byte / 8-byte loads
+  int anchor_vec;      // the anchor colour can be read with one 8-byte load per pixel
+  int cert_ok;         // the constants are mid-range: phase 1 may certify pixels
+  int cx_col, cy_row;  // the column / row with col - cx == 0 / row - cy == 0, or -1
+};
+
+// DPP row/wave reductions: the result is valid in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i(int old, int v) {
+  return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+// `old` (what masked-out rows receive) is the identity of the operation, which
+// lets the compiler fold each step into one DPP-modified ALU instruction.
+__device__ __forceinline__ float wave_sum63(float v) {
+  v += dpp_f<0xB1, 0xF>(0.0f, v);         // quad_perm [1,0,3,2]
+  v += dpp_f<0x4E, 0xF>(0.0f, v);         // quad_perm [2,3,0,1]
+  v += dpp_f<0x141, 0xF>(0.0f, v);        // row_half_mirror
+  v += dpp_f<0x140, 0xF>(0.0f, v);        // row_mirror
+  v += dpp_f<0x142, 0xA>(0.0f, v);        // row_bcast15 into rows 1,3
+  v += dpp_f<0x143, 0xC>(0.0f, v);        // row_bcast31 into rows 2,3
+  return v;
+}
+
+__device__ __forceinline__ unsigned int wave_isum63(unsigned int x) {
+  int v = (int)x;
+  v += dpp_i<0xB1, 0xF>(0, v);
+  v += dpp_i<0x4E, 0xF>(0, v);
+  v += dpp_i<0x141, 0xF>(0, v);
+  v += dpp_i<0x140, 0xF>(0, v);
+  v += dpp_i<0x142, 0xA>(0, v);
+  v += dpp_i<0x143, 0xC>(0, v);
+  return (unsigned int)v;
+}
+
+// LDS cell of one neighbour-frame pixel (8 bytes):
+//   x = half(1024 + R) | half(1024 + G) << 16,  y = half(1024 + B) | raw_depth << 16
+// binary16 has ulp 1 on [1024, 2048), so half(1024 + n) is the bit pattern
+// 0x6400 | n for a byte n: building a cell is byte shuffling, no conversion.
+// Colour differences (exact packed-half subtractions) are free of the bias and
+// each interpolation step is one mixed-precision fma; the bias rides along in
+// the interpolated value and cancels against the equally biased anchor colour.
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
+constexpr unsigned int HALF_BIAS2 = 0x64006400u;   // two halves of 1024.0
+
+__device__ __forceinline__ half2_t as_half2(unsigned int v) { return __builtin_bit_cast(half2_t, v); }
+__device__ __forceinline__ uint2 make_cell(unsigned int r, unsigned int g, unsigned int b, unsigned int depth) {
+  uint2 c;
+  c.x = HALF_BIAS2 | r | (g << 16);
+  c.y = 0x6400u | b | (depth << 16);
+  return c;
+}
+__device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b) {
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_min(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+__device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b) {
+  return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(ushort2_t, a), __builtin_bit_cast(ushort2_t, b)));
+}
+// packed (y << 16 | x) min / max over the first eight lanes, valid in lanes 0..7
+__device__ __forceinline__ unsigned int oct_pk_min(unsigned int v) {
+  v = pk_min_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(-1, (int)v));
+  return pk_min_u16(v, (unsigned int)dpp_i<0x141, 0xF>(-1, (int)v));
+}
+__device__ __forceinline__ unsigned int oct_pk_max(unsigned int v) {
+  v = pk_max_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(0, (int)v));
+  return pk_max_u16(v, (unsigned int)dpp_i<0x141, 0xF>(0, (int)v));
+}
+// packed (y << 16 | x) min / max over the wave, valid in lane 63
+__device__ __forceinline__ unsigned int wave_pk_min63(unsigned int v) {
+  v = pk_min_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x141, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x140, 0xF>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x142, 0xA>(-1, (int)v));
+  v = pk_min_u16(v, (unsigned int)dpp_i<0x143, 0xC>(-1, (int)v));
+  return v;
+}
+__device__ __forceinline__ unsigned int wave_pk_max63(unsigned int v) {
+  v = pk_max_u16(v, (unsigned int)dpp_i<0xB1, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x4E, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x141, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x140, 0xF>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x142, 0xA>(0, (int)v));
+  v = pk_max_u16(v, (unsigned int)dpp_i<0x143, 0xC>(0, (int)v));
+  return v;
+}
+
+struct Acc {   // per-thread partial sums of one neighbour frame
+  float ap, sp, ag, sg;
+};
+
+struct Cells {  // the four taps of one pixel
+  uint2 a, b, c, e;
+};
+
+__device__ __forceinline__ uint2 split64(unsigned long long v) { return make_uint2((unsigned int)v, (unsigned int)(v >> 32)); }
+// the 2 x 2 cells at window index idx, as 8-byte LDS reads
+__device__ __forceinline__ Cells read_cells(const uint2* win, unsigned int idx) {
+  const unsigned long long* c = reinterpret_cast<const unsigned long long*>(win) + idx;
+  Cells t;
+  t.a = split64(c[0]); t.b = split64(c[1]); t.c = split64(c[WIN_PITCH]); t.e = split64(c[WIN_PITCH + 1]);
+  return t;
+}
+
+__device__ __forceinline__ bool taps_nonzero(const Cells& t) {  // all four raw depths != 0
+  return min(min(t.a.y, t.b.y), min(t.c.y, t.e.y)) >= 0x10000u;
+}
+
+// Bilinear blend of one pixel and its contribution to the sums.  Interpolation order as
+// in the oracle (top row, bottom row, then vertical) with fused multiply-adds; the
+// deviation from the unfused float32 oracle is a few 1e-7.  Colour differences are exact
+// in binary16; each horizontal lerp is one mixed-precision fma.  a_rg / a_b: the anchor's
+// colour as biased binary16 patterns, half2(1024 + R, 1024 + G) and half(1024 + B) in the
+// low 16 bits.  z2: the transformed depth (float64).  c_geo counts the pixels that also have
+// four non-zero depth taps.  Runs only on lanes whose pixel warps (warp_valid).
+template <bool UNIT>
+__device__ __forceinline__ void blend_accumulate(Acc& acc, unsigned int& c_geo, const Cells& t, float fu, float fv,
+                                                 float inv_factor_f, unsigned int a_rg, unsigned int a_b, double z2) {
+  const half2_t aRG = as_half2(t.a.x), cRG = as_half2(t.c.x);
+  const half2_t dT = as_half2(t.b.x) - aRG, dB = as_half2(t.e.x) - cRG;
+  const _Float16 aB = as_half2(t.a.y).x, cB = as_half2(t.c.y).x;
+  const _Float16 dTb = as_half2(t.b.y).x - aB, dBb = as_half2(t.e.y).x - cB;
+  const float tr = __builtin_fmaf(fu, (float)dT.x, (float)aRG.x), br = __builtin_fmaf(fu, (float)dB.x, (float)cRG.x);
+  const float tg = __builtin_fmaf(fu, (float)dT.y, (float)aRG.y), bg = __builtin_fmaf(fu, (float)dB.y, (float)cRG.y);
+  const float tb = __builtin_fmaf(fu, (float)dTb, (float)aB), bb = __builtin_fmaf(fu, (float)dBb, (float)cB);
+  const float wr = __builtin_fmaf(fv, br - tr, tr), wg = __builtin_fmaf(fv, bg - tg, tg);
+  const float wb = __builtin_fmaf(fv, bb - tb, tb);
+  // anchor - warped (the sign is irrelevant to |r| and r^2): one mixed-precision fma per channel,
+  // the anchor (same bias of 1024 as the cells) read as binary16 in place
+  float rr, rg, rb;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rr) : "v"(wr), "v"(a_rg));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rg) : "v"(wg), "v"(a_rg));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(wb), "v"(a_b));
+  acc.ap = ((acc.ap + fabsf(rr)) + fabsf(rg)) + fabsf(rb);
+  acc.sp = __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, __builtin_fmaf(rr, rr, acc.sp)));
+  if (taps_nonzero(t)) {   // geo_valid: the depth channel and its residual
+    const float da = (float)(t.a.y >> 16), db = (float)(t.b.y >> 16), dc = (float)(t.c.y >> 16), de = (float)(t.e.y >> 16);
+    const float td = __builtin_fmaf(fu, db - da, da), bd = __builtin_fmaf(fu, de - dc, dc);
+    const float w3 = __builtin_fmaf(fv, bd - td, td);
+    const float wd = UNIT ? w3 : w3 * inv_factor_f;
+    // in float64: test_import's d is float64 and may be far larger than the residual
+    const float g = (float)((double)wd - z2);
+    acc.ag += fabsf(g);
+    acc.sg = __builtin_fmaf(g, g, acc.sg);
+    c_geo += 1u;
+  }
+}
+
+__device__ __forceinline__ uint2 global_cell(const uint16_t* __restrict__ d2, const uint8_t* __restrict__ c2, int W,
+                                             int x, int y) {
+  const int o = y * W + x;
+  return make_cell(c2[3 * o], c2[3 * o + 1], c2[3 * o + 2], d2[o]);
+}
+
+// Projection of one anchor pixel in float32, for window prediction only.
+__device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u0, float v0, float z, float& u,
+                                            float& v, float& z2) {
+  const float x = (u0 - (float)c.cx) * z * __builtin_amdgcn_rcpf((float)c.fx);
+  const float y = (v0 - (float)c.cy) * z * __builtin_amdgcn_rcpf((float)c.fy);
+  const float x2 = x * (float)p.r00 + y * (float)p.r10 + z * (float)p.r20 + (float)p.t0;
+  const float y2 = x * (float)p.r01 + y * (float)p.r11 + z * (float)p.r21 + (float)p.t1;
+  z2 = x * (float)p.r02 + y * (float)p.r12 + z * (float)p.r22 + (float)p.t2;
+  const float rz = __builtin_amdgcn_rcpf(z2);
+  u = x2 * (float)c.fx * rz + (float)c.cx;
+  v = y2 * (float)c.fy * rz + (float)c.cy;
+}
+
+struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned address
+  unsigned int x, y;
+};
+
+template <int TH, bool UNIT>
+__global__ void __launch_bounds__(TPB, (TH >= 32 ? 3 : TH >= 24 ? 4 : 5))
+pair_loss_fused_kernel(const FusedArgs a) {
+  constexpr int RPW = TH / 2;                        // rows a wave (and every lane of it) walks
+  constexpr int WIN_ROWS = win_rows(TH);
+  static_assert(RPW >= 1 && RPW <= 32, "one bit per row in a 32-bit mask");
+  __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
+  __shared__ unsigned int s_rng[4][2];
+  __shared__ int s_winrec[4];
+  __shared__ float s_sum[4][4];
+  __shared__ unsigned int s_cnt[4][4];
+
+  const int H = a.H, W = a.W, k = a.k;
+  const Cam cam = a.cam;
+  // blocks that share (blockIdx % 8) run on one XCD and share its L2: give each
+  // such group whole images so that a tile's halo rows/columns hit in L2.
+  const int tiles = a.tiles_x * a.tiles_y;
+  const int group = blockIdx.x & 7;
+  const int slot = blockIdx.x >> 3;
+  const int b = (slot / tiles) * 8 + group;
+  if (b >= a.B) return;
+  const int tile = slot % tiles;
+  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // known to be wave-uniform
+  const long long HW = (long long)H * W;
+  const int col = tx * TILE_W + (wave & 1) * 64 + lane;
+  const int row0 = ty * TH + (wave >> 1) * RPW;
+  const int colc = min(col, W - 1);          // a column outside the image has no bit in the masks below
+  const uint16_t* d1b = a.depth1 + (long long)b * HW;
+  const uint8_t* c1b = a.rgb1 + 3 * (long long)b * HW;
+
+  // rows of this wave inside the image, and of those the rows with row - cy != 0
+  unsigned int rows_in = 0u, rows_nz = 0u;
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    rows_in |= (row0 + r < H) ? (1u << r) : 0u;
+    rows_nz |= (row0 + r < H && row0 + r != a.cy_row) ? (1u << r) : 0u;
+  }
+  const unsigned long long col_in = __builtin_amdgcn_ballot_w64(col < W);
+  const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
+
+  // ---- anchor pixels of this lane: raw depth and colour {R, G, B, 0}, read once per tile ----
+  unsigned int a_d[RPW], a_rgb[RPW];
+  {
+    const unsigned int d_off = 2u * (unsigned int)colc;
+    if (a.anchor_vec) {
+      // W % 4 == 0 and a 4-byte aligned plane: 3 * (row * W + col) has the alignment of 3 * col in every
+      // row, so one 8-byte load at a fixed per-lane offset holds the pixel's three bytes (the offset is
+      // pulled back at the row's end so that the load stays inside the row)
+      const unsigned int L = 3u * (unsigned int)colc;
+      const unsigned int La = min(L & ~3u, 3u * (unsigned int)W - 8u);
+      const unsigned int s = L - La;   // 0..5
+      const unsigned int sel = s | ((s + 1u) << 8) | ((s + 2u) << 16) | 0x0c000000u;
+      Dword2 q[RPW];
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int rowc = min(row0 + r, H - 1);
+        const char* drow = reinterpret_cast<const char*>(d1b) + 2ll * rowc * W;
+        const char* crow = reinterpret_cast<const char*>(c1b) + 3ll * rowc * W;
+        a_d[r] = *reinterpret_cast<const uint16_t*>(drow + d_off);
+        q[r] = *reinterpret_cast<const Dword2*>(crow + La);
+      }
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) a_rgb[r] = __builtin_amdgcn_perm(q[r].y, q[r].x, sel);
+    } else {
+      const unsigned int c_off = 3u * (unsigned int)colc;
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const int rowc = min(row0 + r, H - 1);
+        const char* drow = reinterpret_cast<const char*>(d1b) + 2ll * rowc * W;
+        const uint8_t* cp = c1b + 3ll * rowc * W + c_off;
+        a_d[r] = *reinterpret_cast<const uint16_t*>(drow + d_off);
+        a_rgb[r] = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
+      }
+    }
+  }
+
+  const float factor_f = (float)cam.factor;
+  const float inv_factor_f = 1.0f / factor_f;
+  const double ucx = (double)col - cam.cx;
+  const double vcy0 = (double)row0 - cam.cy;
+
+  // range of non-zero anchor depth in the tile: found on first need (see below)
+  unsigned int zmn = 0xffffu, zmx = 0u;
+  bool have_range = false;
+
+  for (int j = 0; j < k; ++j) {
+    // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
+    // that depends on them alone is computed for all rows ahead of this loop and held in registers)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
+    asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
+    const long long bj = (long long)b * k + j;
+    const Pose p = load_pose(a.rel + 16 * bj);
+    const uint16_t* d2 = a.depth2 + bj * HW;
+    const uint8_t* c2 = a.rgb2 + 3 * bj * HW;
+
+    // ---- predicted tap window: the tile's corners at the nearest and farthest depth ----
+    // For a fixed depth the tile maps to a convex quadrilateral, and a pixel moves
+    // along a segment as its depth varies, so the eight projected points bound
+    // every tap.  The window is only a cache: a tap outside it is gathered from
+    // global memory, so the prediction (float32, with a margin) affects speed only.
+    // When the translation moves a point at 256 raw depth units by less than half a
+    // pixel, the window does not depend on depth and the tile's depth range is
+    // not needed (a nearer pixel may miss the window and take the slow path).
+    const float shift_px = fmaxf((float)cam.fx, (float)cam.fy) * factor_f * (1.0f / 256.0f) *
+                           (fabsf((float)p.t0) + fabsf((float)p.t1) + fabsf((float)p.t2));
+    const bool depth_free = shift_px < 0.5f;   // NaN: false
+    if (!depth_free && !have_range) {
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        const bool inside = ((rows_in >> r) & 1u) && col < W;
+        const unsigned int dr = inside ? a_d[r] : 0u;
+        zmn = min(zmn, dr ? dr : 0xffffu);
+        zmx = max(zmx, dr);
+      }
+      const unsigned int pk = wave_pk_min63(zmn | 0xffff0000u), px = wave_pk_max63(zmx);
+      if (lane == 63) { s_rng[wave][0] = pk; s_rng[wave][1] = px; }
+      __syncthreads();
+      zmn = min(min(s_rng[0][0], s_rng[1][0]), min(s_rng[2][0], s_rng[3][0])) & 0xffffu;
+      zmx = max(max(s_rng[0][1], s_rng[1][1]), max(s_rng[2][1], s_rng[3][1])) & 0xffffu;
+      have_range = true;
+    }
+    if (wave == 0) {
+      const unsigned int z_near = depth_free ? 256u : zmn, z_far = depth_free ? 65535u : zmx;
+      const bool any_depth = depth_free || zmx != 0u;
+      int wx0 = 0, wy0 = 0, ncols = 0, nrows = 0;
+      if (any_depth) {
+        const int cx_ = (lane & 1) ? min(tx * TILE_W + TILE_W - 1, W - 1) : tx * TILE_W;
+        const int cy_ = (lane & 2) ? min(ty * TH + TH - 1, H - 1) : ty * TH;
+        const float zc = (float)((lane & 4) ? z_far : z_near) * __builtin_amdgcn_rcpf(factor_f);
+        float pu, pv, pz;
+        project_f32(cam, p, (float)cx_, (float)cy_, zc, pu, pv, pz);
+        const bool okp = (lane < 8) && (pz > 0.0f) && (fabsf(pu) < 1e6f) && (fabsf(pv) < 1e6f);   // NaN fails
+        const bool bad = __builtin_amdgcn_ballot_w64((lane < 8) && !okp) != 0ull;
+        const int lo_u = okp ? max((int)floorf(pu) - 2, 0) : 0x7fff, lo_v = okp ? max((int)floorf(pv) - 2, 0) : 0x7fff;
+        const int hi_u = okp ? min((int)floorf(pu) + 3, W - 1) : 0, hi_v = okp ? min((int)floorf(pv) + 3, H - 1) : 0;
+        const unsigned int pmin = oct_pk_min(((unsigned int)min(lo_v, 0x7fff) << 16) | (unsigned int)min(lo_u, 0xffff));
+        const unsigned int pmax = oct_pk_max(((unsigned int)max(hi_v, 0) << 16) | (unsigned int)max(hi_u, 0));
+        const unsigned int bmin = (unsigned int)__builtin_amdgcn_readfirstlane((int)pmin);
+        const unsigned int bmax = (unsigned int)__builtin_amdgcn_readfirstlane((int)pmax);
+        const int bx0 = (int)(bmin & 0xffffu), by0 = (int)(bmin >> 16), bx1 = (int)(bmax & 0xffffu), by1 = (int)(bmax >> 16);
+        if (!bad && bx1 >= bx0 && by1 >= by0 && a.stage_vec) {
+          wx0 = bx0 & ~(CHUNK - 1);
+          wy0 = by0;
+          ncols = min(bx1 + 1 - wx0, WIN_PITCH);   // a larger box is cut: the rest goes the slow way
+          nrows = min(by1 + 1 - wy0, WIN_ROWS);
+          if (ncols < 2 || nrows < 2) ncols = nrows = 0;   // a tap needs two columns and two rows
+        }
+      }
+      if (lane == 0) { s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows; }
+    }
+    __syncthreads();   // also: the previous neighbour's gathers and s_sum / s_cnt reads are done
+    const int wx0 = __builtin_amdgcn_readfirstlane(s_winrec[0]), wy0 = __builtin_amdgcn_readfirstlane(s_winrec[1]);
+    const int ncols = __builtin_amdgcn_readfirstlane(s_winrec[2]), nrows = __builtin_amdgcn_readfirstlane(s_winrec[3]);
+
+    // ---- stage the window: 8-byte cells {half R | half G, half B | raw depth} ----
+    const int chunks_x = (ncols + CHUNK - 1) / CHUNK;
+    const int nchunks = chunks_x * nrows;
+    // chunk c -> (row, chunk in row) by a 16-bit reciprocal: exact for c < 2^16 / chunks_x
+    const unsigned int inv_cx = chunks_x ? (65535u / (unsigned int)chunks_x + 1u) : 0u;
+    // two chunks per thread and pass, both chunks' loads in flight before the first is converted
+    auto chunk_src = [&](int c, uint2*& dst) -> int {
+      const int cr = (int)(((unsigned int)c * inv_cx) >> 16), cc = c - cr * chunks_x;
+      dst = win + cr * WIN_PITCH + cc * CHUNK;
+      return (wy0 + cr) * W + wx0 + cc * CHUNK;   // inside the image, 8-pixel aligned
+    };
+    auto chunk_store = [&](uint2* dst, const uint4 dv, const uint2 q0, const uint2 q1, const uint2 q2) {
+      const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
+      const uint32_t cw[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, 0u};
+#pragma unroll
+      for (int i = 0; i < CHUNK; ++i) {
+        // bytes 3i, 3i+1, 3i+2 of the 24-byte colour group; v_perm_b32 picks bytes
+        // from {hi dword (4..7), lo dword (0..3)}, selector 0x0c gives a zero byte
+        const int br = 3 * i, bg = 3 * i + 1, bb = 3 * i + 2;
+        const int kk = br >> 2;   // R and G lie in dwords kk, kk+1
+        const unsigned int sel_rg = 0x0c000c00u | (unsigned int)(br - 4 * kk) | ((unsigned int)(bg - 4 * kk) << 16);
+        const unsigned int sel_bd = 0x00000c00u | (unsigned int)(bb & 3) | ((4u + 2u * (i & 1)) << 16) | ((5u + 2u * (i & 1)) << 24);
+        uint2 cell;
+        cell.x = __builtin_amdgcn_perm(cw[kk + 1], cw[kk], sel_rg) | HALF_BIAS2;
+        cell.y = __builtin_amdgcn_perm(dw[i >> 1], cw[bb >> 2], sel_bd) | 0x6400u;
+        dst[i] = cell;
+      }
+    };
+#pragma unroll 1
+    for (int c = tid; c < nchunks; c += 2 * TPB) {
+      uint2 *dst0, *dst1;
+      const int o0 = chunk_src(c, dst0);
+      const bool two = c + TPB < nchunks;
+      const int o1 = chunk_src(two ? c + TPB : c, dst1);
+      const uint4 dv0 = *reinterpret_cast<const uint4*>(d2 + o0);
+      const uint2* cp0 = reinterpret_cast<const uint2*>(c2 + 3 * o0);
+      const uint2 p0 = cp0[0], p1 = cp0[1], p2 = cp0[2];
+      const uint4 dv1 = *reinterpret_cast<const uint4*>(d2 + o1);
+      const uint2* cp1 = reinterpret_cast<const uint2*>(c2 + 3 * o1);
+      const uint2 q0 = cp1[0], q1 = cp1[1], q2 = cp1[2];
+      chunk_store(dst0, dv0, p0, p1, p2);
+      if (two) chunk_store(dst1, dv1, q0, q1, q2);
+    }
+    __syncthreads();
+
+    // a tap (du, dv) is in the window when du < lim_u and dv < lim_v (unsigned compares)
+    const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
+
+    Acc acc = {0.f, 0.f, 0.f, 0.f};
+    unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0;
+    unsigned int c_geo = 0u;       // per lane: pixels with four non-zero depth taps (summed over the wave at the end)
+    unsigned int rest_bits = 0u;   // bit r: row r of this lane is left to phase 2
+
+    // ---- certificate of phase 1 (all values wave-uniform) ----
+    // With S = 65535/factor * (axm |r0j| + aym |r1j| + |r2j|) + |tj| (the largest sum of magnitudes in
+    // the transform of coordinate j), the reference's x', y', z' and the ones of phase 1 each differ from
+    // the real-number value by at most 8 resp. 24 roundings of 2^-53 S (constants, the per-row steps,
+    // the fmas).  For z' above delta_z = 2^-16 Sz the projected coordinate therefore moves by at most
+    //   32 * 2^-53 * 2^17 * (fx Sx / Sz + |u - cx|)  <  eps = 2^-28 * ((fx Sx + fy Sy) / Sz + extent)
+    // (the reciprocal's 2^-48 and the final roundings are covered by the slack of 8), and eps_f, the
+    // threshold applied to the float32 fractions, is twice that and at least 2^-20.
+    bool cert = a.cert_ok != 0;
+    float eps_f = 0.f, delta_z = 0.f;
+    {
+      const float zmaxf = 65535.0f * (float)a.inv_fac;
+      const float Sx = zmaxf * (a.axm * fabsf((float)p.r00) + a.aym * fabsf((float)p.r10) + fabsf((float)p.r20)) + fabsf((float)p.t0);
+      const float Sy = zmaxf * (a.axm * fabsf((float)p.r01) + a.aym * fabsf((float)p.r11) + fabsf((float)p.r21)) + fabsf((float)p.t1);
+      const float Sz = zmaxf * (a.axm * fabsf((float)p.r02) + a.aym * fabsf((float)p.r12) + fabsf((float)p.r22)) + fabsf((float)p.t2);
+      delta_z = Sz * 0x1p-16f;
+      const float ratio = ((float)cam.fx * Sx + (float)cam.fy * Sy) / Sz;
+      const float eps = 0x1p-28f * (ratio + a.extent);
+      eps_f = fmaxf(2.0f * eps, 0x1p-20f);
+      cert = cert && (eps_f <= 0x1p-7f) && (delta_z > 0.0f) && (delta_z < 3.0e38f);   // NaN fails
+    }
+    const bool cert_u = __builtin_amdgcn_readfirstlane((int)cert) != 0;   // the same in every lane
+
+    if (cert_u && nrows > 0) {
+      // ---- phase 1: u - wx0 + 1 = (z A + t0') / (z C + t2) + (cx - wx0 + 1) with
+      //   A = (col-cx) r00 + (row-cy) (fx/fy) r10 + fx r20,  C = ((col-cx)/fx) r02 + ((row-cy)/fy) r12 + r22
+      // (all divided by factor: z is the raw depth), likewise v; A, B, C advance by a constant per row ----
+      const double kAc = p.r00 * a.inv_fac, kAr = (a.fx_fy * p.r10) * a.inv_fac, kA0 = (cam.fx * p.r20) * a.inv_fac;
+      const double kBc = (a.fy_fx * p.r01) * a.inv_fac, kBr = p.r11 * a.inv_fac, kB0 = (cam.fy * p.r21) * a.inv_fac;
+      const double kCc = p.r02 * a.inv_fx_fac, kCr = p.r12 * a.inv_fy_fac, kC0 = p.r22 * a.inv_fac;
+      double A = fma(ucx, kAc, fma(vcy0, kAr, kA0));
+      double Bq = fma(ucx, kBc, fma(vcy0, kBr, kB0));
+      double C = fma(ucx, kCc, fma(vcy0, kCr, kC0));
+      const double t0p = cam.fx * p.t0, t1p = cam.fy * p.t1, t2 = p.t2;
+      const double cxw = cam.cx - (double)(wx0 - 1), cyw = cam.cy - (double)(wy0 - 1);
+      const double dz = (double)delta_z;
+      const float half_eps = 0.5f - eps_f;
+      // Software pipeline: row r + 1 is projected and its four cells are requested from LDS before row r
+      // is blended, so that the LDS latency and the projection's dependent float64 chain overlap the
+      // blend of the row before (a row's code is several basic blocks: the compiler cannot do this).
+      struct Row {
+        unsigned long long m_fast;   // lanes finished by phase 1 in this row (their taps are in the window)
+        float fu, fv;
+        double Z;
+        Cells t;
+      };
+      auto project_row = [&](const int r) -> Row {
+        Row o;
+        const unsigned int draw = a_d[r];
+        const double z = (double)draw;
+        const double X = fma(z, A, t0p), Y = fma(z, Bq, t1p), Z = fma(z, C, t2);
+        A += kAr; Bq += kBr; C += kCr;
+        double rz = __builtin_amdgcn_rcp(Z);
+        rz = fma(rz, fma(-Z, rz, 1.0), rz);
+        const double uw = fma(X, rz, cxw), vw = fma(Y, rz, cyw);
+        // the conversion saturates and maps NaN to 0: lanes with wild coordinates fail the window test
+        int tu, tv;
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(tu) : "v"(uw));
+        asm("v_cvt_i32_f64 %0, %1" : "=v"(tv) : "v"(vw));
+        o.fu = (float)__builtin_amdgcn_fract(uw);
+        o.fv = (float)__builtin_amdgcn_fract(vw);
+        o.Z = Z;
+        const unsigned int du = (unsigned int)tu - 1u, dv = (unsigned int)tv - 1u;
+        unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
+        if (!((rows_nz >> r) & 1u)) m_valid0 = 0ull;
+        // certified: z' safely positive and both coordinates farther than the bound from every integer
+        const unsigned long long m_cert = m_valid0 & __builtin_amdgcn_ballot_w64(Z > dz) &
+                                          __builtin_amdgcn_ballot_w64(fmaxf(fabsf(o.fu - 0.5f), fabsf(o.fv - 0.5f)) <= half_eps);
+        o.m_fast = m_cert & __builtin_amdgcn_ballot_w64(du < lim_u) & __builtin_amdgcn_ballot_w64(dv < lim_v);
+        unsigned int idx = __umul24(dv, (unsigned int)WIN_PITCH) + du;
+        asm("" : "+v"(idx));   // keeps the "* 8" of the cell size a shift: the reads are then known to be 8-byte aligned
+        o.t = read_cells(win, __builtin_amdgcn_inverse_ballot_w64(o.m_fast) ? idx : 0u);
+        const unsigned int nf = (unsigned int)__popcll(o.m_fast);
+        n_valid0 += nf; n_inb += nf; n_warp += nf;
+        const unsigned long long m_other = m_valid0 & ~o.m_fast;
+        if (m_other != 0ull) {
+          // Certified pixels outside the window: floor(u) = wx0 + du and floor(v) = wy0 + dv are the
+          // reference's, u and v are no integers, so "0 <= u <= W" is "0 <= floor(u) <= W - 1" and
+          // "u <= W - 1" is "floor(u) <= W - 2" (coordinates too large for int32 wrap or saturate to values
+          // that stay outside).  A pixel outside the image is finished here; one inside it whose taps the
+          // window does not hold, and every uncertified pixel, goes to phase 2.
+          const unsigned int iu = du + (unsigned int)wx0, iv = dv + (unsigned int)wy0;
+          const unsigned long long m_out = m_cert & ~o.m_fast;
+          const unsigned long long m_inb = m_out & __builtin_amdgcn_ballot_w64(iu < (unsigned int)W) &
+                                           __builtin_amdgcn_ballot_w64(iv < (unsigned int)H);
+          const unsigned long long m_wv = m_inb & __builtin_amdgcn_ballot_w64(iu + 1u < (unsigned int)W) &
+                                          __builtin_amdgcn_ballot_w64(iv + 1u < (unsigned int)H);
+          n_valid0 += (unsigned int)__popcll(m_out & ~m_wv);
+          n_inb += (unsigned int)__popcll(m_inb & ~m_wv);
+          const unsigned long long m_rest = (m_valid0 & ~m_cert) | m_wv;
+          if (m_rest != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
+        }
+        return o;
+      };
+      Row cur = project_row(0);
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) {
+        Row nxt = cur;
+        if (r + 1 < RPW) nxt = project_row(r + 1);
+        if (__builtin_amdgcn_inverse_ballot_w64(cur.m_fast)) {
+          const unsigned int argb = a_rgb[r];
+          const unsigned int a_rg = __builtin_amdgcn_perm(0x64u, argb, 0x04010400u);
+          const unsigned int a_b = __builtin_amdgcn_perm(0x64u, argb, 0x0c0c0402u);
+          blend_accumulate<UNIT>(acc, c_geo, cur.t, cur.fu, cur.fv, inv_factor_f, a_rg, a_b, cur.Z);
+        }
+        cur = nxt;
+        __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead: more only lengthens live ranges
+      }
+    } else {
+      // no certificate (constants out of range, a degenerate pose) or no window: every pixel in the image
+      rest_bits = __builtin_amdgcn_inverse_ballot_w64(col_in) ? rows_in : 0u;
+    }
+
+    // ---- phase 2: the reference's exact operation order for the pixels phase 1 left ----
+    if (__builtin_amdgcn_ballot_w64(rest_bits != 0u) != 0ull) {
+      const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
+#pragma unroll 1
+      for (int r = 0; r < RPW; ++r) {
+        const bool need = (rest_bits >> r) & 1u;
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+        bool valid0 = false, inb = false, wv = false;
+        if (need) {
+          const int row = row0 + r;
+          const long long o = (long long)row * W + col;
+          const unsigned int draw = d1b[o];
+          double x, y, z, x2, y2, z2, u, v;
+          backproject_px(cam, col, row, draw, x, y, z);
+          valid0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
+          transform_px(p, x, y, z, x2, y2, z2);
+          project_px(cam, x2, y2, z2, u, v);
+          inb = valid0 && in_window(u, v, dW, dH);
+          wv = valid0 && in_window(u, v, dW1, dH1) && (z2 > 0.0);
+          if (wv) {
+            // 0 <= u <= W - 1 and 0 <= v <= H - 1: truncation is floor
+            const double fl_u = floor(u), fl_v = floor(v);
+            const int iu = (int)fl_u, iv = (int)fl_v;
+            const float fu = (float)(u - fl_u), fv = (float)(v - fl_v);
+            const unsigned int du = (unsigned int)(iu - wx0), dv = (unsigned int)(iv - wy0);
+            Cells t;
+            if (du < lim_u && dv < lim_v) {
+              t = read_cells(win, dv * WIN_PITCH + du);
+            } else {
+              const int x1 = min(iu + 1, W - 1), y1 = min(iv + 1, H - 1);
+              t.a = global_cell(d2, c2, W, iu, iv); t.b = global_cell(d2, c2, W, x1, iv);
+              t.c = global_cell(d2, c2, W, iu, y1); t.e = global_cell(d2, c2, W, x1, y1);
+            }
+            const uint8_t* cp = c1b + 3 * o;
+            const unsigned int rgbx = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
+            const unsigned int a_rg = __builtin_amdgcn_perm(0x64u, rgbx, 0x04010400u);
+            const unsigned int a_b = __builtin_amdgcn_perm(0x64u, rgbx, 0x0c0c0402u);
+            blend_accumulate<UNIT>(acc, c_geo, t, fu, fv, inv_factor_f, a_rg, a_b, z2);
+          }
+        }
+        n_valid0 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(valid0));
+        n_inb += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(inb));
+        n_warp += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(wv));
+      }
+    }
+
+    // ---- reduce: DPP within the wave, LDS across the four waves, one atomic each ----
+    // (64 lanes adding to one LDS word serialise in the LDS pipe and stall the
+    // wave far longer than the 6 DPP steps cost)
+    const float t0 = wave_sum63(acc.ap), t1 = wave_sum63(acc.sp);
+    const float t2s = wave_sum63(acc.ag), t3 = wave_sum63(acc.sg);
+    const unsigned int n_geo = wave_isum63(c_geo);
+    if (lane == 63) {
+      s_sum[wave][0] = t0; s_sum[wave][1] = t1; s_sum[wave][2] = t2s; s_sum[wave][3] = t3;
+      s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; s_cnt[wave][2] = n_warp; s_cnt[wave][3] = n_geo;
+    }
+    __syncthreads();   // also: every gather is done before the next neighbour restages the window
+    if (wave == 0) {
+      PairAcc* pa = a.ws + bj;
+      if (lane < 4) {
+        const double t = ((double)s_sum[0][lane] + (double)s_sum[1][lane]) + ((double)s_sum[2][lane] + (double)s_sum[3][lane]);
+        atomicAdd(&pa->sums[lane], t);
+      } else if (lane < 8) {
+        const int q = lane - 4;
+        atomicAdd(&pa->counts[q], (s_cnt[0][q] + s_cnt[1][q]) + (s_cnt[2][q] + s_cnt[3][q]));
+      }
+      // every add of this workgroup has been performed before its ticket is drawn
+      __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+      unsigned int t = 0;
+      if (lane == 0) t = atomicAdd(&pa->ticket, 1u);
+      t = __builtin_amdgcn_readfirstlane(t);
+      if (t == (unsigned int)tiles - 1u) {
+        // last workgroup of this pair: totals out, accumulators back to zero
+        if (lane < 4) a.sums[bj * SLAMHIP_NSUMS + lane] = atomicExch(&pa->sums[lane], 0.0);
+        else if (lane < 8) a.counts[bj * SLAMHIP_NCOUNTS + (lane - 4)] = atomicExch(&pa->counts[lane - 4], 0u);
+        else if (lane == 8) atomicExch(&pa->ticket, 0u);
+      }
+    }
+    // the next neighbour's first barrier (after the window prediction) orders these reads of s_sum /
+    // s_cnt before that neighbour's writes
+  }
+}
+
+static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+// Argument checks and launch shared by the two fused entry points; `workspace` holds at least
+// B * k zero-filled PairAcc records.
+static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                            const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor, int B,
+                            int k, int H, int W, double* sums, uint32_t* counts, void* workspace, hipStream_t s) {
+  SLAMHIP_REQUIRE(depth1 && rgb1 && depth2 && rgb2 && rel4x4 && K && sums && counts && workspace, SLAMHIP_E_ARG,
+                  "%s: null pointer", who);
+  SLAMHIP_REQUIRE(H <= 32767 && W <= 65535 && (long long)H * W <= 0x20000000LL, SLAMHIP_E_SIZE,
+                  "%s: image larger than 65535 x 32767 or 2^29 pixels", who);
+  SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
+                  aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
+                  "%s: misaligned workspace, input or output", who);
+  static const int tile_h = []() {
+    const char* e = getenv("SLAMHIP_TILE_H");
+    const int v = e ? atoi(e) : 32;
+    return (v == 16 || v == 24) ? v : 32;
+  }();
+  FusedArgs a;
+  a.depth1 = depth1; a.rgb1 = rgb1; a.depth2 = depth2; a.rgb2 = rgb2; a.rel = rel4x4;
+  a.ws = (PairAcc*)workspace; a.sums = sums; a.counts = counts;
+  a.cam = Cam{K[0], K[1], K[2], K[3], factor};
+  a.B = B; a.k = k; a.H = H; a.W = W;
+  a.tiles_x = (W + TILE_W - 1) / TILE_W;
+  a.tiles_y = (H + tile_h - 1) / tile_h;
+  const long long groups = ((long long)B + 7) / 8;
+  const long long nblocks = groups * 8 * a.tiles_x * a.tiles_y;
+  SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "%s: grid too large", who);
+  // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
+  a.stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
+  a.anchor_vec = (W % 4 == 0) && aligned_to(rgb1, 4);
+  // phase 1 assumes that no intermediate comes near the denormal or overflow range ("x, y, z all non-zero"
+  // is then "raw depth, col - cx and row - cy all non-zero"): constants in [2^-64, 2^64], principal point
+  // in [2^-32, 2^32]; its error bound covers the roundings of the quotients below
+  auto mid = [](double v) { const double m = fabs(v); return m >= 0x1p-64 && m <= 0x1p64; };
+  auto pp = [](double v) { const double m = fabs(v); return m >= 0x1p-32 && m <= 0x1p32; };
+  a.cert_ok = mid(K[0]) && mid(K[1]) && mid(factor) && pp(K[2]) && pp(K[3]);
+  a.fx_fy = K[0] / K[1]; a.fy_fx = K[1] / K[0];
+  a.inv_fac = 1.0 / factor; a.inv_fx_fac = 1.0 / (K[0] * factor); a.inv_fy_fac = 1.0 / (K[1] * factor);
+  a.axm = (float)(fmax(fabs(K[2]), fabs((double)(W - 1) - K[2])) / fabs(K[0]) * 1.0001);
+  a.aym = (float)(fmax(fabs(K[3]), fabs((double)(H - 1) - K[3])) / fabs(K[1]) * 1.0001);
+  a.extent = (float)((double)W + (double)H + fabs(K[2]) + fabs(K[3]) + 8.0);
+  auto int_index = [](double c, int n) { return (c >= 0.0 && c < (double)n && c == floor(c)) ? (int)c : -1; };
+  a.cx_col = int_index(K[2], W);
+  a.cy_row = int_index(K[3], H);
+  const bool unit = factor == 1.0;
+  const dim3 grid((unsigned)nblocks), block(TPB);
+  if (tile_h == 16) {
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<16, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<16, false>), grid, block, 0, s, a);
+  } else if (tile_h == 24) {
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<24, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<24, false>), grid, block, 0, s, a);
+  } else {
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<32, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<32, false>), grid, block, 0, s, a);
+  }
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+extern "C" {
+
+size_t slamhip_pair_loss_workspace_bytes(int B, int k) {
+  if (B <= 0 || k <= 0) return 0;
+  return sizeof(PairAcc) * (size_t)B * (size_t)k;
+}
+
+int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                            const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
+                            int B, int k, int H, int W, double* sums, uint32_t* counts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
+                  "pair_loss_fused: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
+  if (B == 0) return SLAMHIP_OK;  // an empty batch has no buffers to check
+  SLAMHIP_REQUIRE(workspace != nullptr, SLAMHIP_E_ARG, "pair_loss_fused: null pointer");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_pair_loss_workspace_bytes(B, k), SLAMHIP_E_SIZE,
+                  "pair_loss_fused: workspace of %zu bytes, need %zu", workspace_bytes,
+                  slamhip_pair_loss_workspace_bytes(B, k));
+  return launch_pair_loss("pair_loss_fused", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W, sums,
+                          counts, workspace, (hipStream_t)stream);
+}
+
+int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(workspace || workspace_bytes == 0, SLAMHIP_E_ARG, "pair_loss_reset_workspace: null workspace");
+  if (workspace_bytes == 0) return SLAMHIP_OK;
+  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream));
+  return SLAMHIP_OK;
+}
+
+// ---- the fused kernel for callers that cannot allocate ---------------------
+// The accumulator records live in a file-scope device array instead of a caller's
+// workspace.  Every GPU holds its own copy of the array at its own address: the
+// address is looked up once per device (with that device current) and only that
+// pointer, never the array's name, is used by host code afterwards.
+static __device__ __align__(256) unsigned char scratch[SLAMHIP_STATIC_MAX_PAIRS * sizeof(PairAcc)];
+constexpr int MAX_DEVICES = 64;
+static std::atomic<void*> scratch_ptr[MAX_DEVICES];
+
+int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
+                                   const uint8_t* rgb2, const double* rel4x4, const double K[4], double factor,
+                                   int B, int k, int H, int W, double* sums, uint32_t* counts, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && k > 0 && H > 0 && W > 0, SLAMHIP_E_ARG,
+                  "pair_loss_fused_static: bad shape B=%d k=%d H=%d W=%d", B, k, H, W);
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE((long long)B * k <= SLAMHIP_STATIC_MAX_PAIRS, SLAMHIP_E_SIZE,
+                  "pair_loss_fused_static: %lld (anchor, neighbour) pairs, the built-in scratch holds %d "
+                  "(use slamhip_pair_loss_fused with a workspace)", (long long)B * k, SLAMHIP_STATIC_MAX_PAIRS);
+  int dev = -1;
+  SLAMHIP_HIP(hipGetDevice(&dev));
+  SLAMHIP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, SLAMHIP_E_SIZE, "pair_loss_fused_static: device %d", dev);
+  void* ptr = scratch_ptr[dev].load(std::memory_order_acquire);
+  if (!ptr) {   // first call on this device (racing first calls look up the same address)
+    SLAMHIP_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+    SLAMHIP_REQUIRE(ptr != nullptr, SLAMHIP_E_HIP, "pair_loss_fused_static: no address for the scratch array");
+    scratch_ptr[dev].store(ptr, std::memory_order_release);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // the array keeps whatever the last call (possibly an interrupted one) left: clear the records of this call
+  SLAMHIP_HIP(hipMemsetAsync(ptr, 0, sizeof(PairAcc) * (size_t)B * (size_t)k, s));
+  return launch_pair_loss("pair_loss_fused_static", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W,
+                          sums, counts, ptr, s);
+}
+
+}  // extern "C"
