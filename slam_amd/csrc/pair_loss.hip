@@ -21,6 +21,7 @@
 // instruction issue; nothing here is GEMM-shaped, so no MFMA.  This file is built
 // with -ffp-contract=off: no product/sum pair is fused except where fma() is written.
 #include <atomic>
+#include <string>
 
 #include "geom_device.h"
 
@@ -50,7 +51,6 @@ namespace slamhip {
 // atomic exchanges, which also leaves the workspace zeroed for the next call: no memset
 // and no second kernel on the stream.
 constexpr int TILE_W = 128;
-constexpr int TPB = 256;
 constexpr int CHUNK = 8;                        // staging granule in pixels (16 B of depth)
 constexpr int WIN_PITCH = 160;                  // LDS window row pitch in cells (multiple of CHUNK)
 // window rows for a tile of th rows: th + 8, one less where that lets four workgroups share a CU's 160 KiB
@@ -257,17 +257,22 @@ struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned
   unsigned int x, y;
 };
 
-template <int TH, bool UNIT>
-__global__ void __launch_bounds__(TPB, (TH >= 32 ? 3 : TH >= 24 ? 4 : 5))
+// waves per SIMD the register allocation must allow: what the LDS windows of TH-row tiles leave room for
+constexpr int fused_waves(int th, int nw) { const int wg = 163840 / (TILE_W + 32) / 8 / win_rows(th); return (wg * nw + 3) / 4 > 8 ? 8 : (wg * nw + 3) / 4; }
+
+template <int TH, int RPW, bool UNIT>
+__global__ void __launch_bounds__(128 * (TH / RPW), fused_waves(TH, 2 * (TH / RPW)))
 pair_loss_fused_kernel(const FusedArgs a) {
-  constexpr int RPW = TH / 2;                        // rows a wave (and every lane of it) walks
+  // RPW: rows a wave (and every lane of it) walks; the tile's TH / RPW row groups x 2 column halves = NW waves
+  constexpr int NW = 2 * (TH / RPW), TPB = 64 * NW;
+  static_assert(TH % RPW == 0 && NW >= 2 && NW <= 4, "two or four waves per tile");
   constexpr int WIN_ROWS = win_rows(TH);
   static_assert(RPW >= 1 && RPW <= 32, "one bit per row in a 32-bit mask");
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
-  __shared__ unsigned int s_rng[4][2];
+  __shared__ unsigned int s_rng[NW][2];
   __shared__ int s_winrec[4];
-  __shared__ float s_sum[4][4];
-  __shared__ unsigned int s_cnt[4][4];
+  __shared__ float s_sum[NW][4];
+  __shared__ unsigned int s_cnt[NW][4];
 
   const int H = a.H, W = a.W, k = a.k;
   const Cam cam = a.cam;
@@ -346,11 +351,6 @@ pair_loss_fused_kernel(const FusedArgs a) {
   bool have_range = false;
 
   for (int j = 0; j < k; ++j) {
-    // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
-    // that depends on them alone is computed for all rows ahead of this loop and held in registers)
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
-    asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
     const long long bj = (long long)b * k + j;
     const Pose p = load_pose(a.rel + 16 * bj);
     const uint16_t* d2 = a.depth2 + bj * HW;
@@ -378,8 +378,9 @@ pair_loss_fused_kernel(const FusedArgs a) {
       const unsigned int pk = wave_pk_min63(zmn | 0xffff0000u), px = wave_pk_max63(zmx);
       if (lane == 63) { s_rng[wave][0] = pk; s_rng[wave][1] = px; }
       __syncthreads();
-      zmn = min(min(s_rng[0][0], s_rng[1][0]), min(s_rng[2][0], s_rng[3][0])) & 0xffffu;
-      zmx = max(max(s_rng[0][1], s_rng[1][1]), max(s_rng[2][1], s_rng[3][1])) & 0xffffu;
+      zmn = 0xffffu; zmx = 0u;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { zmn = min(zmn, s_rng[w][0] & 0xffffu); zmx = max(zmx, s_rng[w][1] & 0xffffu); }
       have_range = true;
     }
     if (wave == 0) {
@@ -420,7 +421,6 @@ pair_loss_fused_kernel(const FusedArgs a) {
     const int nchunks = chunks_x * nrows;
     // chunk c -> (row, chunk in row) by a 16-bit reciprocal: exact for c < 2^16 / chunks_x
     const unsigned int inv_cx = chunks_x ? (65535u / (unsigned int)chunks_x + 1u) : 0u;
-    // two chunks per thread and pass, both chunks' loads in flight before the first is converted
     auto chunk_src = [&](int c, uint2*& dst) -> int {
       const int cr = (int)(((unsigned int)c * inv_cx) >> 16), cc = c - cr * chunks_x;
       dst = win + cr * WIN_PITCH + cc * CHUNK;
@@ -443,21 +443,26 @@ pair_loss_fused_kernel(const FusedArgs a) {
         dst[i] = cell;
       }
     };
-#pragma unroll 1
-    for (int c = tid; c < nchunks; c += 2 * TPB) {
-      uint2 *dst0, *dst1;
-      const int o0 = chunk_src(c, dst0);
-      const bool two = c + TPB < nchunks;
-      const int o1 = chunk_src(two ? c + TPB : c, dst1);
-      const uint4 dv0 = *reinterpret_cast<const uint4*>(d2 + o0);
-      const uint2* cp0 = reinterpret_cast<const uint2*>(c2 + 3 * o0);
-      const uint2 p0 = cp0[0], p1 = cp0[1], p2 = cp0[2];
-      const uint4 dv1 = *reinterpret_cast<const uint4*>(d2 + o1);
-      const uint2* cp1 = reinterpret_cast<const uint2*>(c2 + 3 * o1);
-      const uint2 q0 = cp1[0], q1 = cp1[1], q2 = cp1[2];
-      chunk_store(dst0, dv0, p0, p1, p2);
-      if (two) chunk_store(dst1, dv1, q0, q1, q2);
+    // one pass: every thread has the loads of all its chunks in flight before it converts the first
+    constexpr int NQ = (WIN_PITCH / CHUNK * WIN_ROWS + TPB - 1) / TPB;   // chunks per thread at most
+#ifndef SLAMHIP_ABL_NO_STAGE      // (timing ablation only: results are wrong without the staging)
+    if (nchunks > 0) {
+      uint2* dst[NQ];
+      uint4 dvq[NQ];
+      uint2 cq[NQ][3];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int c = tid + q * TPB;
+        const int o = chunk_src(c < nchunks ? c : 0, dst[q]);
+        dvq[q] = *reinterpret_cast<const uint4*>(d2 + o);
+        const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
+        cq[q][0] = cp[0]; cq[q][1] = cp[1]; cq[q][2] = cp[2];
+      }
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (tid + q * TPB < nchunks) chunk_store(dst[q], dvq[q], cq[q][0], cq[q][1], cq[q][2]);
     }
+#endif
     __syncthreads();
 
     // a tap (du, dv) is in the window when du < lim_u and dv < lim_v (unsigned compares)
@@ -473,9 +478,10 @@ pair_loss_fused_kernel(const FusedArgs a) {
     // the transform of coordinate j), the reference's x', y', z' and the ones of phase 1 each differ from
     // the real-number value by at most 8 resp. 24 roundings of 2^-53 S (constants, the per-row steps,
     // the fmas).  For z' above delta_z = 2^-16 Sz the projected coordinate therefore moves by at most
-    //   32 * 2^-53 * 2^17 * (fx Sx / Sz + |u - cx|)  <  eps = 2^-28 * ((fx Sx + fy Sy) / Sz + extent)
-    // (the reciprocal's 2^-48 and the final roundings are covered by the slack of 8), and eps_f, the
-    // threshold applied to the float32 fractions, is twice that and at least 2^-20.
+    //   32 * 2^-53 * 2^17 * (fx Sx / Sz + |u - cx|)  =  2^-31 * (...)  <  eps = 2^-30 * ((fx Sx + fy Sy) / Sz + extent)
+    // (the reciprocal's 2^-48 and the final roundings are covered by the slack of 2), and eps_f, the
+    // threshold applied to the float32 fractions, is twice that (which also covers pixels up to twice
+    // `extent` away from the principal point) and at least 2^-20.
     bool cert = a.cert_ok != 0;
     float eps_f = 0.f, delta_z = 0.f;
     {
@@ -485,13 +491,23 @@ pair_loss_fused_kernel(const FusedArgs a) {
       const float Sz = zmaxf * (a.axm * fabsf((float)p.r02) + a.aym * fabsf((float)p.r12) + fabsf((float)p.r22)) + fabsf((float)p.t2);
       delta_z = Sz * 0x1p-16f;
       const float ratio = ((float)cam.fx * Sx + (float)cam.fy * Sy) / Sz;
-      const float eps = 0x1p-28f * (ratio + a.extent);
+      const float eps = 0x1p-30f * (ratio + a.extent);
       eps_f = fmaxf(2.0f * eps, 0x1p-20f);
       cert = cert && (eps_f <= 0x1p-7f) && (delta_z > 0.0f) && (delta_z < 3.0e38f);   // NaN fails
     }
     const bool cert_u = __builtin_amdgcn_readfirstlane((int)cert) != 0;   // the same in every lane
 
+    // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
+    // that depends on them alone is computed for all rows ahead of the neighbour loop and held in registers;
+    // here, after the staging, so that the anchor loads stay in flight behind the prediction and the staging)
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
+    asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
+#ifdef SLAMHIP_ABL_NO_PHASE1     // timing ablation only: results are wrong
+    if (false) {
+#else
     if (cert_u && nrows > 0) {
+#endif
       // ---- phase 1: u - wx0 + 1 = (z A + t0') / (z C + t2) + (cx - wx0 + 1) with
       //   A = (col-cx) r00 + (row-cy) (fx/fy) r10 + fx r20,  C = ((col-cx)/fx) r02 + ((row-cy)/fy) r12 + r22
       // (all divided by factor: z is the raw depth), likewise v; A, B, C advance by a constant per row ----
@@ -582,6 +598,9 @@ pair_loss_fused_kernel(const FusedArgs a) {
     }
 
     // ---- phase 2: the reference's exact operation order for the pixels phase 1 left ----
+#ifdef SLAMHIP_ABL_NO_PHASE2   // timing ablation only: results are wrong
+    rest_bits = 0u;
+#endif
     if (__builtin_amdgcn_ballot_w64(rest_bits != 0u) != 0ull) {
       const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
 #pragma unroll 1
@@ -641,12 +660,18 @@ pair_loss_fused_kernel(const FusedArgs a) {
     if (wave == 0) {
       PairAcc* pa = a.ws + bj;
       if (lane < 4) {
-        const double t = ((double)s_sum[0][lane] + (double)s_sum[1][lane]) + ((double)s_sum[2][lane] + (double)s_sum[3][lane]);
+        double t = (double)s_sum[0][lane] + (double)s_sum[1][lane];
+        if (NW == 4) t += (double)s_sum[2][lane] + (double)s_sum[3][lane];
         atomicAdd(&pa->sums[lane], t);
       } else if (lane < 8) {
         const int q = lane - 4;
-        atomicAdd(&pa->counts[q], (s_cnt[0][q] + s_cnt[1][q]) + (s_cnt[2][q] + s_cnt[3][q]));
+        unsigned int c = s_cnt[0][q] + s_cnt[1][q];
+        if (NW == 4) c += s_cnt[2][q] + s_cnt[3][q];
+        atomicAdd(&pa->counts[q], c);
       }
+#ifdef SLAMHIP_ABL_NO_TICKET     // timing ablation only: nothing is published
+      continue;
+#endif
       // every add of this workgroup has been performed before its ticket is drawn
       __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
       unsigned int t = 0;
@@ -682,11 +707,13 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
-  static const int tile_h = []() {
-    const char* e = getenv("SLAMHIP_TILE_H");
-    const int v = e ? atoi(e) : 32;
-    return (v == 16 || v == 24) ? v : 32;
+  // tile shape: 128 x 32 pixels on four waves by default; SLAMHIP_TILE = "16x16" (two waves), "16x8", "24x12" for tuning
+  static const int tile_cfg = []() {
+    const char* e = getenv("SLAMHIP_TILE");
+    const std::string v = e ? e : "";
+    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : 0;
   }();
+  const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
   FusedArgs a;
   a.depth1 = depth1; a.rgb1 = rgb1; a.depth2 = depth2; a.rgb2 = rgb2; a.rel = rel4x4;
   a.ws = (PairAcc*)workspace; a.sums = sums; a.counts = counts;
@@ -715,17 +742,21 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
   const bool unit = factor == 1.0;
-  const dim3 grid((unsigned)nblocks), block(TPB);
-  if (tile_h == 16) {
-    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<16, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<16, false>), grid, block, 0, s, a);
-  } else if (tile_h == 24) {
-    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<24, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<24, false>), grid, block, 0, s, a);
-  } else {
-    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<32, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<32, false>), grid, block, 0, s, a);
+  const dim3 grid((unsigned)nblocks);
+#define SLAMHIP_LAUNCH_FUSED(TH_, RPW_)                                                                              \
+  do {                                                                                                             \
+    const dim3 block(128 * (TH_ / RPW_));                                                                          \
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true>), grid, block, 0, s, a);                  \
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false>), grid, block, 0, s, a);                      \
+  } while (0)
+  switch (tile_cfg) {
+    case 1: SLAMHIP_LAUNCH_FUSED(16, 16); break;
+    case 2: SLAMHIP_LAUNCH_FUSED(16, 8); break;
+    case 3: SLAMHIP_LAUNCH_FUSED(24, 12); break;
+    case 4: SLAMHIP_LAUNCH_FUSED(32, 32); break;
+    default: SLAMHIP_LAUNCH_FUSED(32, 16); break;
   }
+#undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
