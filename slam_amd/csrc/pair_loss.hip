@@ -65,15 +65,7 @@ struct PairAcc {
 };
 static_assert(sizeof(PairAcc) == 64, "PairAcc must stay 64 bytes");
 
-struct FusedArgs {
-  const uint16_t* depth1;
-  const uint8_t* rgb1;
-  const uint16_t* depth2;
-  const uint8_t* rgb2;
-  const double* rel;
-  PairAcc* ws;
-  double* sums;
-  unsigned int* counts;
+struct FusedArgs {   // everything but the pointers (those are __restrict__ kernel parameters of their own)
   Cam cam;
   // host-rounded quotients used by phase 1 only (any rounding is covered by the bound)
   double fx_fy, fy_fx, inv_fac, inv_fx_fac, inv_fy_fac;
@@ -84,6 +76,7 @@ struct FusedArgs {
   int anchor_vec;      // the anchor colour can be read with one 8-byte load per pixel
   int cert_ok;         // the constants are mid-range: phase 1 may certify pixels
   int cx_col, cy_row;  // the column / row with col - cx == 0 / row - cy == 0, or -1
+  unsigned long long* stamps;   // diagnostic builds only
 };
 
 // DPP row/wave reductions: the result is valid in lane 63.
@@ -253,6 +246,15 @@ __device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u
   v = y2 * (float)c.fy * rz + (float)c.cy;
 }
 
+// Diagnostic build only (-DSLAMHIP_STAMPS): the shader clock at the phase boundaries of every workgroup's
+// wave 0, written to a buffer of their own that nothing else reads.
+#ifdef SLAMHIP_STAMPS
+static unsigned long long* g_stamps = nullptr;
+#define SLAMHIP_STAMP(i) do { if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SLAMHIP_STAMP(i) do { } while (0)
+#endif
+
 struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned address
   unsigned int x, y;
 };
@@ -262,7 +264,10 @@ constexpr int fused_waves(int th, int nw) { const int wg = 163840 / (TILE_W + 32
 
 template <int TH, int RPW, bool UNIT>
 __global__ void __launch_bounds__(128 * (TH / RPW), fused_waves(TH, 2 * (TH / RPW)))
-pair_loss_fused_kernel(const FusedArgs a) {
+pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
+                       const uint16_t* __restrict__ depth2, const uint8_t* __restrict__ rgb2,
+                       const double* __restrict__ rel, PairAcc* __restrict__ ws, double* __restrict__ sums,
+                       unsigned int* __restrict__ counts) {
   // RPW: rows a wave (and every lane of it) walks; the tile's TH / RPW row groups x 2 column halves = NW waves
   constexpr int NW = 2 * (TH / RPW), TPB = 64 * NW;
   static_assert(TH % RPW == 0 && NW >= 2 && NW <= 4, "two or four waves per tile");
@@ -288,12 +293,16 @@ pair_loss_fused_kernel(const FusedArgs a) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // known to be wave-uniform
+  SLAMHIP_STAMP(0);   // start
+#ifdef SLAMHIP_STAMPS
+  if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+#endif
   const long long HW = (long long)H * W;
   const int col = tx * TILE_W + (wave & 1) * 64 + lane;
   const int row0 = ty * TH + (wave >> 1) * RPW;
   const int colc = min(col, W - 1);          // a column outside the image has no bit in the masks below
-  const uint16_t* d1b = a.depth1 + (long long)b * HW;
-  const uint8_t* c1b = a.rgb1 + 3 * (long long)b * HW;
+  const uint16_t* d1b = depth1 + (long long)b * HW;
+  const uint8_t* c1b = rgb1 + 3 * (long long)b * HW;
 
   // rows of this wave inside the image, and of those the rows with row - cy != 0
   unsigned int rows_in = 0u, rows_nz = 0u;
@@ -305,8 +314,14 @@ pair_loss_fused_kernel(const FusedArgs a) {
   const unsigned long long col_in = __builtin_amdgcn_ballot_w64(col < W);
   const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
 
-  // ---- anchor pixels of this lane: raw depth and colour {R, G, B, 0}, read once per tile ----
+  // the first neighbour's pose is asked for before anything else: the window prediction waits for it
+  Pose p_next = load_pose(rel + 16 * ((long long)b * k));
+
+  // ---- anchor pixels of this lane: raw depth and the eight bytes that hold the colour, read once per tile;
+  // nothing here waits for the loads: they stay in flight behind the window prediction and the staging ----
   unsigned int a_d[RPW], a_rgb[RPW];
+  Dword2 a_q[RPW];
+  unsigned int a_sel;   // byte selector that turns a_q into {R, G, B, 0}
   {
     const unsigned int d_off = 2u * (unsigned int)colc;
     if (a.anchor_vec) {
@@ -316,31 +331,34 @@ pair_loss_fused_kernel(const FusedArgs a) {
       const unsigned int L = 3u * (unsigned int)colc;
       const unsigned int La = min(L & ~3u, 3u * (unsigned int)W - 8u);
       const unsigned int s = L - La;   // 0..5
-      const unsigned int sel = s | ((s + 1u) << 8) | ((s + 2u) << 16) | 0x0c000000u;
-      Dword2 q[RPW];
+      a_sel = s | ((s + 1u) << 8) | ((s + 2u) << 16) | 0x0c000000u;
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
-        const int rowc = min(row0 + r, H - 1);
-        const char* drow = reinterpret_cast<const char*>(d1b) + 2ll * rowc * W;
-        const char* crow = reinterpret_cast<const char*>(c1b) + 3ll * rowc * W;
+        // (32-bit row offsets: an image has at most 2^29 pixels; scalar base + per-lane 32-bit offset)
+        const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;
+        const char* drow = reinterpret_cast<const char*>(d1b) + (size_t)(2u * rw);
+        const char* crow = reinterpret_cast<const char*>(c1b) + (size_t)(3u * rw);
+#ifdef SLAMHIP_ABL_HALF_ANCHORS   // timing ablation only: a quarter of the anchor loads
+        if (r & 3) { a_d[r] = 1000u + r; a_q[r].x = a_q[r].y = 0x10203040u; continue; }
+#endif
         a_d[r] = *reinterpret_cast<const uint16_t*>(drow + d_off);
-        q[r] = *reinterpret_cast<const Dword2*>(crow + La);
+        a_q[r] = *reinterpret_cast<const Dword2*>(crow + La);
       }
-#pragma unroll
-      for (int r = 0; r < RPW; ++r) a_rgb[r] = __builtin_amdgcn_perm(q[r].y, q[r].x, sel);
     } else {
       const unsigned int c_off = 3u * (unsigned int)colc;
+      a_sel = 0x0c020100u;
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
-        const int rowc = min(row0 + r, H - 1);
-        const char* drow = reinterpret_cast<const char*>(d1b) + 2ll * rowc * W;
-        const uint8_t* cp = c1b + 3ll * rowc * W + c_off;
+        const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;
+        const char* drow = reinterpret_cast<const char*>(d1b) + (size_t)(2u * rw);
+        const uint8_t* cp = c1b + (size_t)(3u * rw) + c_off;
         a_d[r] = *reinterpret_cast<const uint16_t*>(drow + d_off);
-        a_rgb[r] = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
+        a_q[r].x = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
+        a_q[r].y = 0u;
       }
     }
   }
-
+  SLAMHIP_STAMP(1);   // anchor loads issued
   const float factor_f = (float)cam.factor;
   const float inv_factor_f = 1.0f / factor_f;
   const double ucx = (double)col - cam.cx;
@@ -352,9 +370,10 @@ pair_loss_fused_kernel(const FusedArgs a) {
 
   for (int j = 0; j < k; ++j) {
     const long long bj = (long long)b * k + j;
-    const Pose p = load_pose(a.rel + 16 * bj);
-    const uint16_t* d2 = a.depth2 + bj * HW;
-    const uint8_t* c2 = a.rgb2 + 3 * bj * HW;
+    const Pose p = p_next;
+    if (j + 1 < k) p_next = load_pose(rel + 16 * (bj + 1));   // in flight behind this neighbour's work
+    const uint16_t* d2 = depth2 + bj * HW;
+    const uint8_t* c2 = rgb2 + 3 * bj * HW;
 
     // ---- predicted tap window: the tile's corners at the nearest and farthest depth ----
     // For a fixed depth the tile maps to a convex quadrilateral, and a pixel moves
@@ -367,6 +386,9 @@ pair_loss_fused_kernel(const FusedArgs a) {
     const float shift_px = fmaxf((float)cam.fx, (float)cam.fy) * factor_f * (1.0f / 256.0f) *
                            (fabsf((float)p.t0) + fabsf((float)p.t1) + fabsf((float)p.t2));
     const bool depth_free = shift_px < 0.5f;   // NaN: false
+#ifdef SLAMHIP_STAMPS
+    if (__builtin_amdgcn_readfirstlane((int)depth_free) >= 0) SLAMHIP_STAMP(12);   // pose arrived
+#endif
     if (!depth_free && !have_range) {
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
@@ -412,7 +434,9 @@ pair_loss_fused_kernel(const FusedArgs a) {
       }
       if (lane == 0) { s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows; }
     }
+    SLAMHIP_STAMP(2);   // window predicted
     __syncthreads();   // also: the previous neighbour's gathers and s_sum / s_cnt reads are done
+    SLAMHIP_STAMP(3);   // barrier passed
     const int wx0 = __builtin_amdgcn_readfirstlane(s_winrec[0]), wy0 = __builtin_amdgcn_readfirstlane(s_winrec[1]);
     const int ncols = __builtin_amdgcn_readfirstlane(s_winrec[2]), nrows = __builtin_amdgcn_readfirstlane(s_winrec[3]);
 
@@ -440,7 +464,11 @@ pair_loss_fused_kernel(const FusedArgs a) {
         uint2 cell;
         cell.x = __builtin_amdgcn_perm(cw[kk + 1], cw[kk], sel_rg) | HALF_BIAS2;
         cell.y = __builtin_amdgcn_perm(dw[i >> 1], cw[bb >> 2], sel_bd) | 0x6400u;
+#ifdef SLAMHIP_ABL_LINEAR_STAGE   // timing ablation only: lane-contiguous (conflict-free) but wrong cell positions
+        win[(i * 256 + (threadIdx.x & 255)) % (WIN_PITCH * WIN_ROWS)] = cell;
+#else
         dst[i] = cell;
+#endif
       }
     };
     // one pass: every thread has the loads of all its chunks in flight before it converts the first
@@ -458,12 +486,17 @@ pair_loss_fused_kernel(const FusedArgs a) {
         const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
         cq[q][0] = cp[0]; cq[q][1] = cp[1]; cq[q][2] = cp[2];
       }
+      SLAMHIP_STAMP(4);   // staging loads issued
+      asm volatile("s_waitcnt vmcnt(0)");
+      SLAMHIP_STAMP(5);   // ... and landed (diagnostic builds only wait here for all of them)
 #pragma unroll
       for (int q = 0; q < NQ; ++q)
         if (tid + q * TPB < nchunks) chunk_store(dst[q], dvq[q], cq[q][0], cq[q][1], cq[q][2]);
     }
 #endif
+    SLAMHIP_STAMP(6);   // cells written
     __syncthreads();
+    SLAMHIP_STAMP(7);   // barrier passed
 
     // a tap (du, dv) is in the window when du < lim_u and dv < lim_v (unsigned compares)
     const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
@@ -500,8 +533,13 @@ pair_loss_fused_kernel(const FusedArgs a) {
     // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
     // that depends on them alone is computed for all rows ahead of the neighbour loop and held in registers;
     // here, after the staging, so that the anchor loads stay in flight behind the prediction and the staging)
+    unsigned int sel = a_sel;
+    asm volatile("" : "+v"(sel));   // (keeps the byte shuffles below, and with them the wait for the anchor loads, at this point)
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
+    for (int r = 0; r < RPW; ++r) {
+      a_rgb[r] = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel);
+      asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
+    }
     asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
 #ifdef SLAMHIP_ABL_NO_PHASE1     // timing ablation only: results are wrong
     if (false) {
@@ -597,6 +635,7 @@ pair_loss_fused_kernel(const FusedArgs a) {
       rest_bits = __builtin_amdgcn_inverse_ballot_w64(col_in) ? rows_in : 0u;
     }
 
+    SLAMHIP_STAMP(8);   // phase 1 done
     // ---- phase 2: the reference's exact operation order for the pixels phase 1 left ----
 #ifdef SLAMHIP_ABL_NO_PHASE2   // timing ablation only: results are wrong
     rest_bits = 0u;
@@ -646,6 +685,7 @@ pair_loss_fused_kernel(const FusedArgs a) {
       }
     }
 
+    SLAMHIP_STAMP(9);   // phase 2 done
     // ---- reduce: DPP within the wave, LDS across the four waves, one atomic each ----
     // (64 lanes adding to one LDS word serialise in the LDS pipe and stall the
     // wave far longer than the 6 DPP steps cost)
@@ -657,8 +697,9 @@ pair_loss_fused_kernel(const FusedArgs a) {
       s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; s_cnt[wave][2] = n_warp; s_cnt[wave][3] = n_geo;
     }
     __syncthreads();   // also: every gather is done before the next neighbour restages the window
+    SLAMHIP_STAMP(10);  // all waves reduced
     if (wave == 0) {
-      PairAcc* pa = a.ws + bj;
+      PairAcc* pa = ws + bj;
       if (lane < 4) {
         double t = (double)s_sum[0][lane] + (double)s_sum[1][lane];
         if (NW == 4) t += (double)s_sum[2][lane] + (double)s_sum[3][lane];
@@ -679,10 +720,14 @@ pair_loss_fused_kernel(const FusedArgs a) {
       t = __builtin_amdgcn_readfirstlane(t);
       if (t == (unsigned int)tiles - 1u) {
         // last workgroup of this pair: totals out, accumulators back to zero
-        if (lane < 4) a.sums[bj * SLAMHIP_NSUMS + lane] = atomicExch(&pa->sums[lane], 0.0);
-        else if (lane < 8) a.counts[bj * SLAMHIP_NCOUNTS + (lane - 4)] = atomicExch(&pa->counts[lane - 4], 0u);
+        if (lane < 4) sums[bj * SLAMHIP_NSUMS + lane] = atomicExch(&pa->sums[lane], 0.0);
+        else if (lane < 8) counts[bj * SLAMHIP_NCOUNTS + (lane - 4)] = atomicExch(&pa->counts[lane - 4], 0u);
         else if (lane == 8) atomicExch(&pa->ticket, 0u);
       }
+      SLAMHIP_STAMP(11);  // ticket drawn
+#ifdef SLAMHIP_STAMPS
+      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+#endif
     }
     // the next neighbour's first barrier (after the window prediction) orders these reads of s_sum /
     // s_cnt before that neighbour's writes
@@ -715,8 +760,7 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   }();
   const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
   FusedArgs a;
-  a.depth1 = depth1; a.rgb1 = rgb1; a.depth2 = depth2; a.rgb2 = rgb2; a.rel = rel4x4;
-  a.ws = (PairAcc*)workspace; a.sums = sums; a.counts = counts;
+  PairAcc* ws = (PairAcc*)workspace;
   a.cam = Cam{K[0], K[1], K[2], K[3], factor};
   a.B = B; a.k = k; a.H = H; a.W = W;
   a.tiles_x = (W + TILE_W - 1) / TILE_W;
@@ -732,6 +776,11 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   // in [2^-32, 2^32]; its error bound covers the roundings of the quotients below
   auto mid = [](double v) { const double m = fabs(v); return m >= 0x1p-64 && m <= 0x1p64; };
   auto pp = [](double v) { const double m = fabs(v); return m >= 0x1p-32 && m <= 0x1p32; };
+#ifdef SLAMHIP_STAMPS
+  a.stamps = g_stamps;
+#else
+  a.stamps = nullptr;
+#endif
   a.cert_ok = mid(K[0]) && mid(K[1]) && mid(factor) && pp(K[2]) && pp(K[3]);
   a.fx_fy = K[0] / K[1]; a.fy_fx = K[1] / K[0];
   a.inv_fac = 1.0 / factor; a.inv_fx_fac = 1.0 / (K[0] * factor); a.inv_fy_fac = 1.0 / (K[1] * factor);
@@ -746,8 +795,10 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
 #define SLAMHIP_LAUNCH_FUSED(TH_, RPW_)                                                                              \
   do {                                                                                                             \
     const dim3 block(128 * (TH_ / RPW_));                                                                          \
-    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true>), grid, block, 0, s, a);                  \
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false>), grid, block, 0, s, a);                      \
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true>), grid, block, 0, s, a, depth1, rgb1,    \
+                                 depth2, rgb2, rel4x4, ws, sums, counts);                                          \
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false>), grid, block, 0, s, a, depth1, rgb1,        \
+                            depth2, rgb2, rel4x4, ws, sums, counts);                                               \
   } while (0)
   switch (tile_cfg) {
     case 1: SLAMHIP_LAUNCH_FUSED(16, 16); break;
@@ -762,6 +813,11 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
 }
 
 extern "C" {
+
+#ifdef SLAMHIP_STAMPS
+// diagnostic builds only: 16 x uint64 per workgroup (device memory); NULL switches the stamps off
+void slamhip_debug_set_stamps(unsigned long long* p) { g_stamps = p; }
+#endif
 
 size_t slamhip_pair_loss_workspace_bytes(int B, int k) {
   if (B <= 0 || k <= 0) return 0;
