@@ -306,3 +306,46 @@ def test_workspace_recovery(fp):
     torch.cuda.synchronize()
     assert np.array_equal(_u32(c), _u32(want_c))
     np.testing.assert_allclose(s.cpu().numpy(), want_s.cpu().numpy(), rtol=1e-12)
+
+
+def test_decision_boundaries_adversarial(fp):
+    """Projected coordinates placed within 1e-12 .. 1e-6 pixels of integers (and so of every decision the
+    reference takes: 0, W-1, W, H-1, H and the floor that picks the taps): a constant-depth anchor under a
+    pure translation t = ((m + d) Z / fx, (n + e) Z / fy, 0) has u = col + m + d, v = row + n + e up to
+    rounding.  The fused kernel may not certify such pixels with its cheap projection: masks, counts and
+    tap choice (n_geo, the sums) must still be the oracle's, bit for bit / within tolerance."""
+    H, W = 48, 64
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    Z = 5000
+    offs = [0.0, 1e-12, -1e-12, 1e-10, -1e-10, 1e-9, -1e-9, 1e-8, -1e-7, 1e-6, -1e-6, 3e-6]
+    shifts = [(0, 0), (3, -2), (-5, 4), (W - 2, 1), (-(W - 3), -(H - 2)), (1, H - 1)]
+    rels, B = [], 0
+    for i, d in enumerate(offs):
+        for (m, n) in shifts[: 3 if i > 6 else 6]:
+            e = offs[(i * 5 + 3) % len(offs)]
+            T = np.eye(4)
+            T[0, 3] = (m + d) * Z / K[0]
+            T[1, 3] = (n + e) * Z / K[1]
+            rels.append(T)
+            B += 1
+    rel = np.stack(rels).reshape(B, 1, 4, 4)
+    rs = np.random.RandomState(7)
+    d1 = np.full((B, H, W), Z, np.uint16)
+    d1[:, ::7, ::5] = 0                                   # some invalid anchors
+    d1[B // 2:, 1::2, :] = 2 * Z                          # a second depth: half of those rows land mid-pixel
+    d2 = rs.randint(2500, 25001, size=(B, 1, H, W)).astype(np.uint16)
+    d2[rs.uniform(size=d2.shape) < 0.1] = 0
+    c1 = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
+    for factor in (1.0,):
+        o = _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+        _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+    # the construction does what it says: most valid pixels sit within 1e-5 of an integer coordinate
+    u = o["uvd"][..., 0]
+    near = np.abs(u - np.round(u)) < 1e-5
+    assert near[np.isfinite(u)].mean() > 0.5
+    # metric depth as well (the divisions by the factor are part of the exact path)
+    rel5 = rel.copy()
+    rel5[:, :, :3, 3] /= 5000.0
+    _check_warp(fp, d1, c1, d2, c2, rel5, K, 5000.0)
+    _check_fused(fp, d1, c1, d2, c2, rel5, K, 5000.0)
