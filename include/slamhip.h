@@ -316,6 +316,14 @@ int slamhip_adam_step_shadow(float* param, const float* grad, float* m, float* v
                              float beta1, float beta2, float eps, int step, float grad_scale,
                              void* shadow_bf16, long long shadow_n, void* stream);
 
+/* The same update for a training step that is recorded once in a HIP graph and replayed (the kernel
+ * arguments of a replayed launch are frozen): lr_t_dev points to one float in device memory holding
+ * lr * sqrt(1 - beta2^step) / (1 - beta1^step) of the current step, which the caller rewrites before
+ * every replay.  Same arithmetic as slamhip_adam_step_shadow (cnn_model.py:146-160). */
+int slamhip_adam_step_dev(float* param, const float* grad, float* m, float* v, long long n,
+                          const float* lr_t_dev, float beta1, float beta2, float eps, float grad_scale,
+                          void* shadow_bf16, long long shadow_n, void* stream);
+
 /* ---- device: input preparation of the RGB-D trainers --------------------------
  * slam/network/model_input.py:427-450 + :360-362,517-522 for a batch of raw frames
  * resident in HBM: rgb uint8 [B,Hs,Ws,3], depth uint16 [B,Hs,Ws] ->

@@ -96,6 +96,8 @@ SIGNATURES = {
     "slamhip_pad_cast_bf16": ([_c_void_p] * 2 + [ctypes.c_longlong, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_adam_step": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 + [_c_int, ctypes.c_float,
                                                                                           _c_void_p], _c_int),
+    "slamhip_adam_step_dev": ([_c_void_p] * 4 + [ctypes.c_longlong, _c_void_p] + [ctypes.c_float] * 4 +
+                              [_c_void_p, ctypes.c_longlong, _c_void_p], _c_int),
     "slamhip_adam_step_shadow": ([_c_void_p] * 4 + [ctypes.c_longlong] + [ctypes.c_float] * 4 +
                                  [_c_int, ctypes.c_float, _c_void_p, ctypes.c_longlong, _c_void_p], _c_int),
 }

@@ -2062,9 +2062,10 @@ __global__ void posenet_loss_kernel(const float* __restrict__ out, const float* 
 __global__ void __launch_bounds__(256)
 adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
             long long n, float lr_t, float beta1, float beta2, float eps, float grad_scale,
-            bf16* __restrict__ shadow, long long shadow_n) {
+            bf16* __restrict__ shadow, long long shadow_n, const float* __restrict__ lr_t_dev) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
+  if (lr_t_dev) lr_t = *lr_t_dev;   // the step size of a launch replayed from a HIP graph lives in device memory
   const float gi = g[i] * grad_scale;
   const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
   const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
@@ -2704,7 +2705,7 @@ int slamhip_adam_step(float* param, const float* grad, float* m, float* v, long 
   if (n == 0) return SLAMHIP_OK;
   const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
-                     beta1, beta2, eps, grad_scale, (bf16*)nullptr, 0LL);
+                     beta1, beta2, eps, grad_scale, (bf16*)nullptr, 0LL, (const float*)nullptr);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -2718,7 +2719,20 @@ int slamhip_adam_step_shadow(float* param, const float* grad, float* m, float* v
   if (n == 0) return SLAMHIP_OK;
   const float lr_t = lr * sqrtf(1.0f - powf(beta2, (float)step)) / (1.0f - powf(beta1, (float)step));
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, lr_t,
-                     beta1, beta2, eps, grad_scale, (bf16*)shadow_bf16, shadow_n);
+                     beta1, beta2, eps, grad_scale, (bf16*)shadow_bf16, shadow_n, (const float*)nullptr);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_adam_step_dev(float* param, const float* grad, float* m, float* v, long long n, const float* lr_t_dev,
+                          float beta1, float beta2, float eps, float grad_scale, void* shadow_bf16,
+                          long long shadow_n, void* stream) {
+  SLAMHIP_REQUIRE(param && grad && m && v && lr_t_dev && n >= 0, SLAMHIP_E_ARG, "adam_step_dev: bad argument");
+  SLAMHIP_REQUIRE(shadow_n >= 0 && shadow_n <= n && (shadow_bf16 || shadow_n == 0), SLAMHIP_E_ARG,
+                  "adam_step_dev: shadow of %lld elements for %lld parameters", shadow_n, n);
+  if (n == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, 0.0f,
+                     beta1, beta2, eps, grad_scale, (bf16*)shadow_bf16, shadow_n, lr_t_dev);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -56,3 +56,13 @@ def total_pair_sums(sums, counts):
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return s, c
+
+
+def agree_min(value, device=None):
+    """The smallest `value` (an int) over the ranks: every rank must run the same number of training
+    steps, because every step issues the gradient all-reduces."""
+    if not initialised():
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())

@@ -18,6 +18,7 @@ import os
 import numpy as np
 import torch
 
+from slam_amd import distributed as dp
 from slam_amd.network import checkpoint
 from slam_amd.network.cnn_model import VGG16Model
 from slam_amd.network.model_config import get_config_provider
@@ -81,7 +82,12 @@ def main(argv=None, model_class=VGG16Model):
     steps, loss_value = 0, float("nan")
     for step in range(epoch):
         logger.info('Executing step:%d', step)
-        for i, sequence_batch in enumerate(input_provider.complete_seq_iter()):
+        sequence_iter = input_provider.complete_seq_iter()
+        if world > 1:
+            # every rank walks a sequence of its own choice (its data shard), and the sequences differ in
+            # length: all ranks stop after the shortest, or the gradient all-reduces would stop matching
+            sequence_iter.sequence_length = dp.agree_min(sequence_iter.sequence_length, device=dev)
+        for i, sequence_batch in enumerate(sequence_iter):
             if a.gpu_prep:
                 rgb = torch.from_numpy(np.stack([f[0] for f in sequence_batch.rgbd_images])).to(dev)
                 depth = torch.from_numpy(np.stack([f[1] for f in sequence_batch.rgbd_images])).to(dev)
@@ -99,7 +105,8 @@ def main(argv=None, model_class=VGG16Model):
                 break
         if step % 10 == 0 and local == 0:
             logger.info('Saving weights.')
-            checkpoint.save(weights_file, vgg_model.params, vgg_model.global_step)
+            checkpoint.save(weights_file, dict(vgg_model.params, **checkpoint.optimizer_slots(vgg_model)),
+                            vgg_model.global_step)
         logger.info('epoc:%d, loss:%s', step, loss_value)
         if a.max_steps and steps >= a.max_steps:
             break

@@ -7,6 +7,19 @@ import os
 import torch
 
 
+def optimizer_slots(model):
+    """The optimizer's per-parameter state of a VGG16Model as named tensors (tf.train.Saver stores the
+    slot variables with the weights): Adam's two moments or RMSProp's mean square, flat buffers in the
+    layout of model.flat_params.  Pass the result to save() / restore() merged with model.params to make
+    a run resumable."""
+    slots = {}
+    for name, attr in (("optimizer/adam_m", "_adam_m"), ("optimizer/adam_v", "_adam_v"), ("optimizer/rms", "_rms")):
+        t = getattr(model, attr, None)
+        if t is not None:
+            slots[name] = t
+    return slots
+
+
 def save(filename, named_variables, global_step=None):
     os.makedirs(os.path.dirname(filename) or ".", exist_ok=True)
     payload = {k: v.detach().cpu().clone() for k, v in named_variables.items()}

@@ -56,7 +56,7 @@ def model_flops(batch, height, width, in_channels=4, fc_dim=4096, output_dim=6):
     return fwd, 3 * fwd - first
 
 
-def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, data_seed=0):
+def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, data_seed=0, graph=None):
     """Random-initialised encoder on synthetic input: `steps` training steps (forward, loss,
     backward, gradient all-reduce when torch.distributed is initialised, Adam) timed with
     one event pair on the launching stream.  Returns a dict for benchmark reports."""
@@ -68,6 +68,11 @@ def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, 
     model.add_loss(torch.eye(6, device=dev), 0.1 * torch.randn(batch, 6, device=dev, generator=g))
     step = model.add_optimizer()
     model._optimizer.learning_rate = 1e-5
+    from .. import distributed as dp
+    if graph is None:    # replay a recorded step wherever it is supported: one GPU, Adam
+        graph = not (dp.initialised() and dp.world_size() > 1) and model._optimizer.kind == 'AdamOptimizer'
+    if graph:
+        step = model.capture_train_step(warmup=max(1, warmup))
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -97,7 +102,7 @@ def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, 
     fwd_bwd_ms = timed(forward_backward)
     forward_ms = timed(model.forward)
     _, flops = model_flops(batch, height, width, 4, model.fc_dim, 6)
-    return dict(batch_per_gpu=batch, step_ms=step_ms, fwd_bwd_ms=fwd_bwd_ms, forward_ms=forward_ms,
+    return dict(batch_per_gpu=batch, step_ms=step_ms, fwd_bwd_ms=fwd_bwd_ms, forward_ms=forward_ms, hip_graph=bool(graph),
                 images_per_s_per_gpu=batch / (step_ms * 1e-3),
                 tflop_per_step=flops / 1e12, achieved_tflops_per_gpu=flops / 1e12 / (step_ms * 1e-3),
                 loss=float(model.loss), parameters=int(model.total_weights))
@@ -280,6 +285,10 @@ class VGG16Model:
         checkpoint, a hand-made update): the bf16 operand copies are rebuilt before the next forward."""
         self._operands_stale = True
         self._fc_shadow_fresh = False
+        if getattr(self, "_graph", None) is not None:
+            # a recorded step cannot see this flag: bring the operand copies up to date now
+            self._refresh_operands()
+            self._operands_stale = True
 
     def _refresh_operands(self):
         for a in self._act[1:]:
@@ -510,6 +519,54 @@ class VGG16Model:
         self.backward_with_allreduce()
         self._apply_gradients(1.0 / dp.world_size())
         return self.loss
+
+    def capture_train_step(self, warmup=2):
+        """The training step recorded once in a HIP graph and replayed: a step is some 250 kernel
+        launches whose host cost (a ctypes call each) otherwise leaves the GPU idle between them.
+        Single GPU and Adam only (the gradient all-reduce and the other optimizers stay on the eager
+        path).  The first `warmup` steps run eagerly (they are ordinary training steps and allocate every
+        buffer the recording needs).  Returns the callable that runs one step; the caller refills
+        `network_input`, the ground truth and the loss weight in place as before.  The learning rate of every step is written to
+        device memory ahead of the replay (kernel arguments are frozen in a graph)."""
+        from .. import distributed as dp
+        if dp.initialised() and dp.world_size() > 1:
+            raise RuntimeError("capture_train_step: the data-parallel step is not captured; use train_step()")
+        if getattr(self, "_optimizer", None) is None or self._optimizer.kind != 'AdamOptimizer':
+            raise RuntimeError("capture_train_step: call add_optimizer() with Adam first")
+        if self.trace is not None:
+            raise RuntimeError("capture_train_step: tracing keeps per-step copies; switch it off")
+        for _ in range(max(1, warmup)):      # every lazily allocated buffer exists before the capture
+            self.train_step()
+        self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._lr_t_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._operands_stale = True          # the operand refresh after an update belongs to every step
+
+        def body():
+            self.forward()
+            self.compute_loss(with_gradient=True)
+            self.backward()
+            ops.adam_step_dev(self.flat_params, self.flat_grads, self._adam_m, self._adam_v, self._lr_t_dev,
+                              shadow=self._fc_shadow)
+            self._operands_stale, self._fc_shadow_fresh = True, True
+
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=self.device)
+        torch.cuda.synchronize(self.device)
+        with torch.cuda.graph(graph, stream=side):
+            body()
+        self._graph = graph
+
+        def step():
+            o = self._optimizer
+            lr = o.learning_rate(self.global_step) if callable(o.learning_rate) else o.learning_rate
+            self._lr_t_host[0] = ops.adam_lr_t(lr, self.global_step + 1)
+            self._lr_t_dev.copy_(self._lr_t_host, non_blocking=True)
+            graph.replay()
+            self.global_step += 1
+            return self.loss
+
+        self.apply_gradient_op = step
+        return step
 
     @time_it(drain_gpu=True)
     def start_training(self, max_steps):

@@ -230,6 +230,25 @@ def adam_step(param, grad, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, gra
               float(beta1), float(beta2), float(eps), int(step), float(grad_scale), capi.ptr(shadow), shadow.numel())
 
 
+def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
+    """The bias-corrected step size of Adam's update number `step` (>= 1), in float32 as the library computes it."""
+    import numpy as np
+    f = np.float32
+    return float(f(lr) * np.sqrt(f(1) - np.power(f(beta2), f(step))) / (f(1) - np.power(f(beta1), f(step))))
+
+
+def adam_step_dev(param, grad, m, v, lr_t_dev, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, shadow=None):
+    """adam_step with the bias-corrected step size read from one float of device memory (`lr_t_dev`):
+    the form a training step recorded in a HIP graph uses."""
+    n = _chk(param, F32, "param").numel()
+    for t in (grad, m, v):
+        assert _chk(t, F32, "adam tensor").numel() == n
+    assert _chk(lr_t_dev, F32, "lr_t_dev").numel() >= 1
+    _call("slamhip_adam_step_dev", capi.ptr(param), capi.ptr(grad), capi.ptr(m), capi.ptr(v), n, capi.ptr(lr_t_dev),
+          float(beta1), float(beta2), float(eps), float(grad_scale), capi.ptr(shadow),
+          0 if shadow is None else shadow.numel())
+
+
 def sgd_step(param, grad, lr, grad_scale=1.0):
     n = _chk(param, F32, "param").numel()
     assert _chk(grad, F32, "grad").numel() == n

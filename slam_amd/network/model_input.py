@@ -106,7 +106,8 @@ class QueuedInputProvider:
         for filename in self.training_filenames:
             associations = np.loadtxt(os.path.join(filename, "associate.txt"), dtype="str", unpack=False)
             groundtruth = np.loadtxt(os.path.join(filename, "groundtruth.txt"), dtype="str", unpack=False)
-            twist, rgb_filepaths, depth_filepaths = self._get_data(associations, groundtruth, sequence_length)
+            twist, rgb_filepaths, depth_filepaths = self._get_data(associations, groundtruth, sequence_length,
+                                                                   base_dir=filename)
             self._queues.append(dict(rgb=[os.path.join(filename, f) for f in rgb_filepaths],
                                      depth=[os.path.join(filename, f) for f in depth_filepaths],
                                      twist=np.asarray(twist, np.float64), pos=0))
@@ -151,13 +152,16 @@ class QueuedInputProvider:
         from ..preprocess import geometry
         return geometry._backtransform_pointcloud(pointcloud, dataset_int)
 
-    def _get_data(self, associations, groundtruth, sequence_length, dynamic_drop=0.0, static_drop=1, rng=np.random):
+    def _get_data(self, associations, groundtruth, sequence_length, dynamic_drop=0.0, static_drop=1, rng=np.random,
+                  base_dir=None):
         """model_input.py:243-319: as preprocess.geometry._get_data with the clamped twist.
         The reference's drop branch cannot run (undefined names at :269, :279); here it
-        runs the overlap test of preprocess.geometry._get_data."""
+        runs the overlap test of preprocess.geometry._get_data.  base_dir: the sequence directory
+        the depth paths of `associations` are relative to (test_import.py:204 joins them the same way)."""
         from ..preprocess import geometry
+        reader = self.image_reader if base_dir is None else (lambda p: self.image_reader(os.path.join(base_dir, p)))
         return geometry._get_data(associations, groundtruth, sequence_length, dynamic_drop, static_drop,
-                                  read_depth=self.image_reader, rng=rng, clamp=True)
+                                  read_depth=reader, rng=rng, clamp=True)
 
 
 class SimpleInputProvider:
@@ -218,7 +222,9 @@ class SimpleInputProvider:
         for seq_dir in self.sequence_dirs:
             associations = np.loadtxt(os.path.join(seq_dir, "associate.txt"), dtype="str", unpack=False)
             groundtruth = np.loadtxt(os.path.join(seq_dir, "groundtruth.txt"), dtype="str", unpack=False)
-            rows = np.array([groundtruth[:, 1:][min(_find_label(groundtruth[:, 0], stamp), len(groundtruth) - 1)]
+            # a frame stamp beyond the last ground-truth stamp raises IndexError, as in the reference
+            # (model_input.py:388 with :122-123): bisect_left may return len(groundtruth)
+            rows = np.array([groundtruth[:, 1:][_find_label(groundtruth[:, 0], stamp)]
                              for stamp in associations[:, 0]]).astype(np.float32)
             self.seq_dir_map[seq_dir] = dict(associations=associations, groundtruth=groundtruth,
                                              relpos=absolute_twist_labels(rows))

@@ -227,3 +227,97 @@ def test_no_batch_norm_variant_trains():
     assert rel_l2(model._act[0]["y"].permute(0, 3, 1, 2), want) < 5e-3
     losses = [float(step()) for _ in range(6)]
     assert np.all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def _fresh_model(seed=1):
+    from slam_amd.network.cnn_model import VGG16Model
+    B, H, W = 4, 64, 64
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, H, W, 4, generator=g).to(torch.bfloat16).float().cuda()
+    model = VGG16Model(B, x, 6, 1e-3, fc_dim=256, seed=seed)
+    model.build_graph()
+    model.add_loss(torch.eye(6).cuda(), torch.randn(B, 6, generator=g).cuda())
+    return model
+
+
+def test_graph_replayed_step_equals_eager_step():
+    """capture_train_step(): the step recorded in a HIP graph does what the eager step does from the same
+    state (same launches; the staircase learning rate reaches the replayed Adam kernel through device
+    memory).  Compared step by step from a restored state: the randomly initialised network amplifies the
+    last-bit differences of float atomics over several steps, so whole trajectories are not comparable."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    m = _fresh_model()
+    m.add_optimizer(optimizer='AdamOptimizer')
+    m._optimizer.learning_rate = lambda s: 1e-4 * 0.1 ** (s // 5)     # the schedule changes inside the run
+    step_g = m.capture_train_step(warmup=2)
+    assert m.global_step == 2
+    deltas = {}
+    for start in (2, 4, 5):       # the update of step 6 (global_step 5) uses a ten times smaller rate
+        m.global_step = start
+        state = [t.clone() for t in (m.flat_params, m._adam_m, m._adam_v)]
+
+        def restore():
+            for t, c in zip((m.flat_params, m._adam_m, m._adam_v), state):
+                t.copy_(c)
+            m.global_step = start
+            m.parameters_changed()
+
+        loss_g = float(step_g())
+        p_g = m.flat_params.clone()
+        assert m.global_step == start + 1
+        restore()
+        loss_e = float(m.train_step())
+        p_e = m.flat_params.clone()
+        assert abs(loss_g - loss_e) <= 2e-3 * abs(loss_e), (start, loss_g, loss_e)
+        d_g, d_e = (p_g - state[0]).double(), (p_e - state[0]).double()
+        assert float((d_g - d_e).norm() / d_e.norm()) < 2e-2, start
+        deltas[start] = float(d_g.norm())
+        restore()
+    assert 5.0 < deltas[4] / deltas[5] < 20.0, deltas     # the rate fell by ten between the two updates
+
+
+def test_sgd_and_rmsprop_follow_the_tensorflow_formulas():
+    """slam/network/cnn_model.py:167-170: GradientDescentOptimizer p -= lr g; RMSPropOptimizer with
+    TensorFlow's defaults (decay 0.9, momentum 0, epsilon 1e-10 inside the root, mean square starting at
+    one): ms = 0.9 ms + 0.1 g^2, p -= lr g / sqrt(ms + 1e-10).  Three updates each, against float64."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from slam_amd.network import encoder_ops as ops
+    g = torch.Generator().manual_seed(11)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    grads = [torch.randn(n, generator=g) * s for s in (1.0, 1e-3, 30.0)]
+    lr, scale = 0.01, 0.5
+    # SGD
+    p = p0.clone().cuda()
+    want = p0.double()
+    for gr in grads:
+        ops.sgd_step(p, gr.cuda(), lr, grad_scale=scale)
+        want = want - lr * (gr.double() * scale)
+    np.testing.assert_allclose(p.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    # RMSProp
+    p = p0.clone().cuda()
+    ms = torch.ones(n).cuda()
+    want, wms = p0.double(), torch.ones(n, dtype=torch.float64)
+    for gr in grads:
+        ops.rmsprop_step(p, gr.cuda(), ms, lr, grad_scale=scale)
+        gs = gr.double() * scale
+        wms = 0.9 * wms + 0.1 * gs * gs
+        want = want - lr * gs / torch.sqrt(wms + 1e-10)
+    np.testing.assert_allclose(ms.cpu().numpy(), wms.numpy(), rtol=1e-5)
+    np.testing.assert_allclose(p.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-6)
+    # and through the model: the configuration's optimizer names select them
+    for kind in ('GradientDescentOptimizer', 'RMSPropOptimizer'):
+        m = _fresh_model(seed=4)
+        step = m.add_optimizer(optimizer=kind)
+        m._optimizer.learning_rate = 1e-4
+        before = m.flat_params.clone()
+        m.forward(); m.compute_loss(); m.backward()
+        grad = m.flat_grads.clone()
+        m._apply_gradients(1.0)
+        if kind == 'GradientDescentOptimizer':
+            want = before.double() - 1e-4 * grad.double()
+        else:
+            want = before.double() - 1e-4 * grad.double() / torch.sqrt(0.9 + 0.1 * grad.double() ** 2 + 1e-10)
+        np.testing.assert_allclose(m.flat_params.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=1e-7)

@@ -117,8 +117,28 @@ def _rank_main(rank, world, port, out_dir):
         h1 = dp.start_bucket_allreduce(flat, 0, 4)
         h2 = dp.start_bucket_allreduce(flat, 4, 10)
         dp.finish([h1, h2])
+        # (3) the trainers' per-epoch step count: every rank walks a sequence of its own (lengths differ)
+        #     and all stop after the shortest, so that the per-step all-reduces keep matching
+        from slam_amd.network import model_input as mi
+        names = ["seq_a", "seq_b"]
+        base = os.path.join(out_dir, "data%d" % rank)
+        for i, nme in enumerate(names):
+            mi.write_synthetic_sequence(os.path.join(base, nme), n_frames=4 + 3 * i, height=24, width=32, seed=i)
+        prov = mi.get_simple_input_provider(lambda: names, base_data_dir=base)
+        prov.sequence_dirs.sort()
+        prov.sequence_dirs = prov.sequence_dirs[rank:] + prov.sequence_dirs[:rank]   # rank r starts on sequence r
+        import random
+        random.shuffle = lambda x: None      # complete_seq_iter() then takes sequence_dirs[0]
+        it = prov.complete_seq_iter()
+        own = it.sequence_length
+        it.sequence_length = dp.agree_min(it.sequence_length)
+        steps = 0
+        for _ in it:
+            g = torch.ones(3) * (rank + 1)
+            dist.all_reduce(g)               # stands for the step's gradient all-reduce
+            steps += 1
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tot_s=tot_s.numpy(), tot_c=tot_c.numpy(),
-                 flat=flat.numpy(), shard=np.array([b, e]))
+                 flat=flat.numpy(), shard=np.array([b, e]), own_len=own, steps=steps)
     finally:
         dist.destroy_process_group()
 
@@ -138,4 +158,5 @@ def test_two_rank_gloo_sharding_and_reductions(tmp_path):
         assert np.array_equal(g["tot_c"], want_c)
         np.testing.assert_array_equal(g["flat"], np.arange(10, dtype=np.float32) * 3)   # (1 + 2) x
         shards.append(tuple(g["shard"]))
+        assert int(g["steps"]) == 4 and int(g["own_len"]) == (4, 7)[r]    # both ranks stop after the shorter sequence
     assert shards == [(0, 3), (3, 5)]

@@ -92,3 +92,15 @@ def test_posenet_input_provider(tmp_path):
     full = mi.resize_bilinear(mi.read_png(os.path.join(d, "seq1", "frame00000.png")), 256, int(np.round(480 * 256.0 / 270)))
     assert full.shape[:2] == (256, 455)
     np.testing.assert_array_equal(img, full[31:255, 230:454])
+
+
+def test_stamp_past_the_ground_truth_raises_like_the_reference(tmp_path):
+    """slam/network/model_input.py:388 with :122-123: bisect_left on the ground-truth stamps may return
+    len(groundtruth), and the reference then fails with IndexError; no silent reuse of the last pose."""
+    d = tmp_path / "seq"
+    mi.write_synthetic_sequence(str(d), n_frames=4, height=24, width=32, seed=0)
+    gt_file = d / "groundtruth.txt"
+    rows = [l for l in gt_file.read_text().splitlines() if l and not l.startswith("#")]
+    gt_file.write_text("\n".join(rows[:-1]) + "\n")        # the last frame's stamp now lies past the ground truth
+    with pytest.raises(IndexError):
+        mi.get_simple_input_provider(lambda: ["seq"], base_data_dir=str(tmp_path))
