@@ -54,6 +54,12 @@ def parse():
     ap.add_argument("--size", default="480x640", help="frame size HxW (960x1280 = the high-resolution configuration)")
     ap.add_argument("--neighbours", type=int, default=1, help="neighbour frames warped per anchor (k)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the CPU baseline (0 = skip)")
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="untimed launches for this long before the warm-up steps: the shader clock needs some "
+                         "50 ms of load to leave its idle state, far more than a few warm-up steps last")
+    ap.add_argument("--train-steps", type=int, default=5,
+                    help="steps of the whole training loop (input preparation, encoder step, frame-pair losses) "
+                         "timed after the headline measurement and reported under 'train_step' (0 = skip)")
     ap.add_argument("--encoder-steps", type=int, default=10,
                     help="training steps of the pose-regression encoder timed after the headline "
                          "measurement and reported under the 'encoder' key (0 = skip)")
@@ -79,7 +85,62 @@ def cpu_baseline(d1, c1, d2, c2, rel, K, factor, budget_s, threads=1):
                                                      "OpenMP over pairs, %d threads" % threads)), sums, counts
 
 
+def counters_for(json_path, source_path):
+    """A committed counter measurement, or None when the source file it was taken on has changed since."""
+    import hashlib
+    if not (os.path.exists(json_path) and os.path.exists(source_path)):
+        return None
+    rec = json.load(open(json_path))
+    sha = hashlib.sha256(open(source_path, "rb").read()).hexdigest()
+    return rec if rec.get("source_sha256") == sha else None
+
+
+def train_loop(fp, buf, K, factor, steps):
+    """prep -> encoder step -> frame-pair losses on the same B pairs; per-stage split from events."""
+    from slam_amd.network import prep
+    from slam_amd.network.cnn_model import VGG16Model
+    d1, c1, d2, c2, rel = buf
+    B = d1.shape[0]
+    dev = d1.device
+    rgb = torch.cat([c1, c2[:, 0]], 0).contiguous()          # 2 B raw frames
+    depth = torch.cat([d1, d2[:, 0]], 0).contiguous()
+    x = torch.zeros(2 * B, 224, 224, 4, dtype=torch.float32, device=dev)
+    model = VGG16Model(2 * B, x, 6, 1e-3, seed=0)
+    model.build_graph()
+    model.add_loss(torch.eye(6, device=dev), torch.zeros(2 * B, 6, device=dev))
+    model.add_optimizer(optimizer='AdamOptimizer')
+    model._optimizer.learning_rate = 1e-5
+    step = model.capture_train_step(warmup=2)
+    plan = fp.PairLossPlan(d1, c1, d2, c2, rel, K, factor)
+
+    def one(ev=None):
+        prep.rgbd_batch(rgb, depth, (224, 224), out=x)
+        if ev: ev[1].record()
+        step()
+        if ev: ev[2].record()
+        plan.run()
+        if ev: ev[3].record()
+
+    for _ in range(2):
+        one()
+    torch.cuda.synchronize()
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
+    t0 = time.perf_counter()
+    for e in evs:
+        e[0].record()
+        one(e)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    split = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in evs]).mean(0)
+    return {"workload": "per step: slamhip_prep_rgbd of %d raw 640x480 frames -> encoder training step (batch %d, "
+                        "HIP graph) -> fused frame-pair kernel on the %d pairs they form" % (2 * B, 2 * B, B),
+            "pairs_per_s": B * steps / el, "step_ms": el / steps * 1e3, "steps": steps,
+            "stage_ms": {"prep": float(split[0]), "encoder_step": float(split[1]), "pair_loss": float(split[2])},
+            "loss_finite": bool(torch.isfinite(model.loss).all())}
+
+
 def main():
+    status = 0
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -129,6 +190,13 @@ def main():
     def step(i):
         return plans[i % len(plans)].run()
 
+    # clock ramp: launches that are neither warm-up nor timed steps (reported in config)
+    ramp_launches, t_ramp = 0, time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < a.ramp_ms:
+        for i in range(50):
+            step(i)
+        torch.cuda.synchronize()
+        ramp_launches += 50
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -176,11 +244,29 @@ def main():
                        "fwd_bwd_ms": enc["fwd_bwd_ms"], "forward_ms": enc["forward_ms"],
                        "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                     "frac": tfl / peak, "flops": "model FLOPs of the whole step / step time, per GPU"}}
+            encoder["hip_graph"] = bool(enc.get("hip_graph"))
+            mfma = counters_for(os.path.join(ROOT, "profiles", "r2_encoder_mfma.json"),
+                                os.path.join(ROOT, "slam_amd", "csrc", "encoder.hip"))
+            if mfma is not None:   # MFMA-busy share of the step's kernel time, from rocprofv3 --pmc (tools/pmc_encoder.sh)
+                encoder["roofline"]["mfma_busy_frac"] = mfma["mfma_busy_frac_of_step"]
+                encoder["roofline"]["mfma_busy_source"] = "profiles/r2_encoder_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per kernel, time-weighted)"
             if world == 1 and rank == 0 and a.cpu_seconds > 0:
                 from oracle import torch_encoder
                 encoder["cpu_baseline"] = torch_encoder.timed_training_steps(8, budget_s=a.cpu_seconds)
-        except Exception as e:   # the headline line must survive a failure here
+                encoder["cpu_baseline_forward"] = torch_encoder.timed_forward(8, budget_s=a.cpu_seconds / 2)
+        except Exception as e:   # the headline line must survive a failure here (the exit code reports it)
             encoder = {"error": "%s: %s" % (type(e).__name__, e)}
+
+    # Secondary measurement (never part of `value`): the whole training loop of slam/main/vgg16_rgbd.py:46-57
+    # with the frame-pair losses beside it.  A step takes `B` frame pairs = 2 B raw frames resident in HBM:
+    # input preparation of the 2 B frames (slamhip_prep_rgbd) -> encoder training step on them -> fused
+    # frame-pair kernel on the B pairs.
+    train = None
+    if a.train_steps > 0 and world == 1 and (k, H, W) == (1, 480, 640):
+        try:
+            train = train_loop(fp, bufs[0], K, a.factor, a.train_steps)
+        except Exception as e:
+            train = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         # the last step ran on bufs[(steps-1) % nb]; check its first pair against the C oracle
@@ -206,13 +292,16 @@ def main():
             verified = bool(np.array_equal(got_c, o_c.astype(np.int64)) and
                             np.allclose(sums[:n].cpu().numpy(), o_s, rtol=1e-4))
         # HBM bytes per launch from the PMC counters: measured with tools/pmc_traffic.sh (separate
-        # rocprofv3 --pmc passes, gfx950 corrections applied) for this same workload and committed;
-        # reported only when the workload matches the one it was measured on
+        # rocprofv3 --pmc passes, corrected as calibrated on this kernel's access mix) for this same workload
+        # and committed together with the hash of the kernel source it was measured on; reported only when
+        # both the workload and the source still match
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r1_traffic_fused.json")
-        if os.path.exists(tpath) and (B, k, H, W) == (64, 1, 480, 640) and a.factor == 1.0 and a.depth == "plane":
-            traffic = json.load(open(tpath))["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r1_traffic_fused.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, mean of 110 launches)"
+        tr = counters_for(os.path.join(ROOT, "profiles", "r2_traffic_fused.json"),
+                          os.path.join(ROOT, "slam_amd", "csrc", "pair_loss.hip"))
+        if tr is not None and (B, k, H, W) == (64, 1, 480, 640) and a.factor == 1.0 and a.depth == "plane":
+            traffic = tr["hbm_bytes_per_launch"]
+            traffic_src = "profiles/r2_traffic_fused.json (rocprofv3 --pmc FETCH_SIZE x %.2f + WRITE_SIZE; kernel source %s)" % (
+                tr.get("fetch_size_factor", 2.0), tr["source_sha256"][:12])
         pairs = world * B * k * a.steps
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         line = {
@@ -233,7 +322,7 @@ def main():
                                    % ("configs[1]: " if (k, H, W) == (1, 480, 640) else "", W, H, B, k,
                                       "" if k == 1 else "s", a.depth, a.factor),
                        "pairs_per_gpu_per_step": B * k, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world,
-                       "streams": max(1, a.streams)},
+                       "streams": max(1, a.streams), "ramp_ms": a.ramp_ms, "ramp_launches": ramp_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
@@ -243,11 +332,19 @@ def main():
             "cpu_baseline_all_cores": cb_all,
             "verified_against_oracle": verified,
             "encoder": encoder,
+            "train_step": train,
         }
         print(json.dumps(line))
+        if verified is False:
+            print("bench: the last step's results do not match the oracle", file=sys.stderr)
+            status = 1
+        if (encoder or {}).get("error") or (train or {}).get("error"):
+            print("bench: a secondary measurement failed: %s" % ((encoder or {}).get("error") or train.get("error")), file=sys.stderr)
+            status = 1
     if dist is not None:
         dist.destroy_process_group()
+    return status
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

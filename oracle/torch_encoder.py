@@ -80,3 +80,23 @@ def timed_training_steps(batch, budget_s=10.0, height=224, width=224, seed=0):
     return dict(value=steps * batch / el, unit="images/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d training steps (forward + backward, no optimizer) at batch %d in %.1f s, "
                        "oracle/torch_encoder.py, PyTorch float32 CPU" % (steps, batch, el))
+
+
+def timed_forward(batch, budget_s=5.0, height=224, width=224, seed=0):
+    """The forward pass alone on the host, float32 (the pose-net forward of the CPU-runnable configuration)."""
+    P = random_params(height, width, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, height, width, 4, generator=g)
+    gt = 0.1 * torch.randn(batch, 6, generator=g)
+    Wl = torch.eye(6)
+    steps, t0 = 0, time.perf_counter()
+    with torch.no_grad():
+        while True:
+            forward_loss(P, x, gt, Wl, 1e-3)
+            steps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s:
+                break
+    return dict(value=steps * batch / el, unit="images/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d forward passes at batch %d in %.1f s, oracle/torch_encoder.py, PyTorch float32 CPU"
+                       % (steps, batch, el))

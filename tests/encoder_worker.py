@@ -1,0 +1,121 @@
+"""Child process of tests/test_encoder_fullsize_gpu.py (the library reads its dispatch switches once per
+process, and a process group is set up before the first GPU call, so both need a process of their own).
+
+  python tests/encoder_worker.py fullsize OUT.npz      forward + loss + backward at batch 128, 224x224, full width
+  python tests/encoder_worker.py layers OUT.npz        every layer's kernels on seeded inputs of its real shape, one layer at a time
+  python tests/encoder_worker.py nccl1 OUT.npz         train_step() under an RCCL process group of one
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def sample_idx(n, count, seed):
+    rs = np.random.RandomState(seed)
+    return np.unique(rs.randint(0, n, size=count))
+
+
+def fullsize(out):
+    import torch
+    from slam_amd.network.cnn_model import VGG16Model
+    B = int(os.environ.get("WORKER_BATCH", "128"))
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, 224, 224, 4, generator=g).to(dev)
+    model = VGG16Model(B, x, 6, 1e-3, seed=5)
+    model.build_graph()
+    model.add_loss(torch.eye(6, device=dev), (0.1 * torch.randn(B, 6, generator=g)).to(dev))
+    model.forward()
+    model.compute_loss(with_gradient=True)
+    model.backward()
+    torch.cuda.synchronize()
+    rec = {"loss": model.loss.cpu().numpy(), "output": model.network_output.cpu().numpy()}
+    for i, a in enumerate(model._act):
+        z = a["z"].reshape(-1)
+        idx = torch.from_numpy(sample_idx(z.numel(), 8192, 100 + i)).to(dev)
+        rec["z_" + a["name"]] = z[idx].float().cpu().numpy()
+    for name, gr in model.grads.items():
+        f = gr.reshape(-1)
+        idx = torch.from_numpy(sample_idx(f.numel(), 20000, 7)).to(dev)
+        rec["g_" + name.replace("/", "__")] = f[idx].float().cpu().numpy()
+        rec["n_" + name.replace("/", "__")] = np.array([float(f.double().norm())])
+    np.savez(out, **rec)
+
+
+def layers(out):
+    """Each convolution layer by itself at its real shape on the same seeded operands in every process:
+    forward with statistics, filter gradient, input gradient; the dense layers' products."""
+    import torch
+    from slam_amd.network import encoder_ops as ops
+    from slam_amd.network.cnn_model import VGG16Model
+    B = int(os.environ.get("WORKER_BATCH", "128"))
+    dev = torch.device("cuda:0")
+    x = torch.zeros(B, 224, 224, 4, device=dev)
+    model = VGG16Model(B, x, 6, 1e-3, seed=5)
+    model.build_graph()
+    torch.manual_seed(11)
+    rec = {}
+
+    def keep(key, t, count=16384, seed=3):
+        f = t.reshape(-1)
+        idx = torch.from_numpy(sample_idx(f.numel(), count, seed)).to(dev)
+        rec[key] = f[idx].float().cpu().numpy()
+
+    for i, a in enumerate(model._act):
+        n = a["name"]
+        if i == 0:
+            continue          # the 4-channel layer has one kernel only
+        prev = model._act[i - 1]
+        h = prev["pooled"] if prev["pool"] else prev["y"]
+        h.copy_(torch.randn(h.shape, device=dev).clamp_(min=0))          # post-ReLU-like input
+        ops.conv3x3_stats(h, model._w_fwd[n], a["z"], a["sums"], model._stats_ws)
+        keep("z_" + n, a["z"])
+        rec["sums_" + n] = a["sums"].cpu().numpy()
+        dz = torch.empty_like(a["z"]).copy_(torch.randn(a["z"].shape, device=dev))
+        ops.wgrad(h, dz, model.grads[n + "/weights"])
+        rec["dw_" + n] = model.grads[n + "/weights"].cpu().numpy()
+        d_in = torch.empty_like(h)
+        ops.conv3x3(dz, model._w_dgrad[n], out_bf16=d_in, flip=True)
+        keep("din_" + n, d_in)
+        del dz, d_in
+    torch.cuda.synchronize()
+    np.savez(out, **rec)
+
+
+def nccl1(out):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", os.environ.get("WORKER_PORT", "29533"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))   # before any GPU call
+    from slam_amd import distributed as dp
+    from slam_amd.network.cnn_model import VGG16Model
+
+    def run(steps):
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4, 64, 64, 4, generator=g).to(dev)
+        model = VGG16Model(4, x, 6, 1e-3, fc_dim=256, seed=1)
+        model.build_graph()
+        model.add_loss(torch.eye(6, device=dev), torch.randn(4, 6, generator=g).to(dev))
+        step = model.add_optimizer(optimizer='AdamOptimizer')
+        model._optimizer.learning_rate = 1e-4
+        losses = [float(step()) for _ in range(steps)]
+        torch.cuda.synchronize()
+        return losses, model.flat_params.cpu().numpy(), model.flat_grads.cpu().numpy()
+
+    assert dp.initialised() and dp.world_size() == 1
+    l_dp, p_dp, g_dp = run(3)            # backward_with_allreduce: two bucketed all-reduces over RCCL
+    dist.destroy_process_group()
+    assert not dp.initialised()
+    l_1, p_1, g_1 = run(3)               # the same steps without a process group
+    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), p_dp=p_dp, p_1=p_1, g_dp=g_dp, g_1=g_1)
+
+
+if __name__ == "__main__":
+    {"fullsize": fullsize, "layers": layers, "nccl1": nccl1}[sys.argv[1]](sys.argv[2])

@@ -28,6 +28,8 @@ def main():
     model.add_loss(torch.eye(6, device=dev), gt)
     step = model.add_optimizer()
     model._optimizer.learning_rate = 1e-5
+    if os.environ.get("ENC_GRAPH", "1") != "0":     # the step replayed from a HIP graph (ENC_GRAPH=0: eager launches)
+        step = model.capture_train_step(warmup=2)
     for _ in range(2):
         step()
     torch.cuda.synchronize()
@@ -55,7 +57,7 @@ def main():
         "forward_achieved_tflops": f_fwd / 1e12 / (fwd_ms * 1e-3),
         "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
         "mfma_frac": f_all / 1e12 / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
-        "loss": float(model.loss), "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 1e9}))
+        "hip_graph": os.environ.get("ENC_GRAPH", "1") != "0", "loss": float(model.loss), "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 1e9}))
 
 
 if __name__ == "__main__":
