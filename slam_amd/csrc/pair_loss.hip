@@ -720,9 +720,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       t = __builtin_amdgcn_readfirstlane(t);
       if (t == (unsigned int)tiles - 1u) {
         // last workgroup of this pair: totals out, accumulators back to zero
-        if (lane < 4) sums[bj * SLAMHIP_NSUMS + lane] = atomicExch(&pa->sums[lane], 0.0);
-        else if (lane < 8) counts[bj * SLAMHIP_NCOUNTS + (lane - 4)] = atomicExch(&pa->counts[lane - 4], 0u);
-        else if (lane == 8) atomicExch(&pa->ticket, 0u);
+        // (the lane number is made opaque here: the output addresses are otherwise computed ahead of the
+        // neighbour loop and, with every register taken by the rows, kept in scratch memory)
+        unsigned int pl = (unsigned int)lane;
+        asm volatile("" : "+v"(pl));
+        if (pl < 4) sums[bj * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
+        else if (pl < 8) counts[bj * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
+        else if (pl == 8) atomicExch(&pa->ticket, 0u);
       }
       SLAMHIP_STAMP(11);  // ticket drawn
 #ifdef SLAMHIP_STAMPS

@@ -57,6 +57,7 @@ def layers(out):
     x = torch.zeros(B, 224, 224, 4, device=dev)
     model = VGG16Model(B, x, 6, 1e-3, seed=5)
     model.build_graph()
+    model._refresh_operands()        # the bfloat16 weight operands (forward() does this on its first call)
     torch.manual_seed(11)
     rec = {}
 
@@ -110,11 +111,12 @@ def nccl1(out):
         return losses, model.flat_params.cpu().numpy(), model.flat_grads.cpu().numpy()
 
     assert dp.initialised() and dp.world_size() == 1
-    l_dp, p_dp, g_dp = run(3)            # backward_with_allreduce: two bucketed all-reduces over RCCL
+    l_dp, p_dp, g_dp = run(1)            # backward_with_allreduce: two bucketed all-reduces over RCCL
+    l_dp3, _, _ = run(3)
     dist.destroy_process_group()
     assert not dp.initialised()
-    l_1, p_1, g_1 = run(3)               # the same steps without a process group
-    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), p_dp=p_dp, p_1=p_1, g_dp=g_dp, g_1=g_1)
+    l_1, p_1, g_1 = run(1)               # the same step without a process group
+    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), p_dp=p_dp, p_1=p_1, g_dp=g_dp, g_1=g_1, l_dp3=np.array(l_dp3))
 
 
 if __name__ == "__main__":

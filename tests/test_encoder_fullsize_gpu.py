@@ -40,17 +40,27 @@ def _rel(a, b):
 def test_batch_128_default_dispatch_against_fallback_kernels(tmp_path):
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     default = _worker("fullsize", str(tmp_path / "default.npz"))
+    again = _worker("fullsize", str(tmp_path / "again.npz"))
     fallback = _worker("fullsize", str(tmp_path / "fallback.npz"), FALLBACK_ENV)
     assert np.isfinite(default["loss"]).all() and np.isfinite(fallback["loss"]).all()
-    keys = [k for k in default.files if k.startswith(("z_", "g_", "n_"))]
-    assert len([k for k in keys if k.startswith("z_")]) == 13
-    worst = {k: _rel(default[k], fallback[k]) for k in keys}
-    worst["loss"], worst["output"] = _rel(default["loss"], fallback["loss"]), _rel(default["output"], fallback["output"])
-    print("default dispatch vs fallback kernels, relative L2:", {k: round(v, 5) for k, v in worst.items()})
-    # The two runs round different sums to bfloat16, and thirteen normalised layers of a randomly
-    # initialised network amplify that: the bound is on the whole pass, the per-layer test below is tight.
-    assert worst["loss"] < 2e-2 and worst["output"] < 6e-2
-    bad = {k: v for k, v in worst.items() if not v < 0.15}
+    keys = [k for k in default.files if k.startswith(("z_", "g_", "n_"))] + ["loss", "output"]
+    assert len([k for k in keys if k.startswith("z_")]) == 12
+    err = {k: _rel(default[k], fallback[k]) for k in keys}
+    floor = {k: _rel(default[k], again[k]) for k in keys}
+    print("default dispatch vs fallback kernels, relative L2:", {k: round(v, 5) for k, v in err.items()})
+    print("default dispatch, two runs, relative L2:", {k: round(v, 5) for k, v in floor.items()})
+    # Two runs of one dispatch already differ: the channel statistics are summed with float atomics, a
+    # difference in the last bit flips bfloat16 roundings of z and y, and twelve normalised layers of a
+    # randomly initialised network amplify that in both directions.  The comparison therefore bounds
+    # the fallback's distance by that run-to-run distance (the layer-by-layer test below is the tight one).
+    assert err["loss"] < 1e-2 and err["output"] < 6e-2
+    assert all(err["z_" + a] < 6e-2 for a in ("conv1_1", "conv1_2", "conv2_1", "conv5_3"))
+    # (measured: z 1e-4 at conv1_2 growing to 3e-2 at conv5_3, output 2.5e-2, dense-layer gradients 2e-2,
+    # convolution gradients 0.1 .. 0.4 in direction at equal norms, for two runs of the same dispatch alike;
+    # the run-to-run distance of the gradients itself varies by some 0.1 between pairs of runs)
+    def bound(k):
+        return 2.0 * floor[k] + 0.1 if k.startswith(("g_conv", "n_conv")) else 3.0 * floor[k] + 1e-2
+    bad = {k: (v, floor[k]) for k, v in err.items() if not v < bound(k)}
     assert not bad, bad
 
 
@@ -60,7 +70,7 @@ def test_batch_128_each_layer_default_dispatch_against_fallback_kernels(tmp_path
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     default = _worker("layers", str(tmp_path / "default.npz"))
     fallback = _worker("layers", str(tmp_path / "fallback.npz"), FALLBACK_ENV)
-    assert len(default.files) == 4 * 12
+    assert len(default.files) == 4 * 11
     worst = {k: _rel(default[k], fallback[k]) for k in default.files}
     print("per layer, default dispatch vs fallback kernels, relative L2:", {k: round(v, 6) for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v < (2e-3 if k.startswith(("z_", "din_")) else 1e-3)}
@@ -107,6 +117,10 @@ def test_train_step_under_rccl_group_of_one(tmp_path):
     backward_with_allreduce() issues the two bucketed all-reduces; the steps match those without a group."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
     r = _worker("nccl1", str(tmp_path / "nccl1.npz"), {"WORKER_PORT": str(29500 + os.getpid() % 400)})
-    np.testing.assert_allclose(r["l_dp"], r["l_1"], rtol=2e-2)
-    assert _rel(r["p_dp"], r["p_1"]) < 1e-3
+    # one step from the same start (later steps of this small random network drift apart through the
+    # order of the float atomics alone, with or without a group)
+    np.testing.assert_allclose(r["l_dp"], r["l_1"], rtol=2e-3)
     assert np.isfinite(r["g_dp"]).all() and np.abs(r["g_dp"]).max() > 0
+    assert _rel(r["g_dp"], r["g_1"]) < 2e-2
+    assert _rel(r["p_dp"], r["p_1"]) < 1e-3
+    assert np.isfinite(r["l_dp3"]).all() and r["l_dp3"][-1] < r["l_dp3"][0]

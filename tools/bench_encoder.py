@@ -1,7 +1,8 @@
 """Times the encoder training step (forward + loss + backward + Adam) at the
 configuration the baseline names for it: batch 128, 224x224x4 input, bfloat16
 operands.  Prints one JSON line with images/s, the model FLOPs per step and the
-fraction of the dense bf16 MFMA peak.  ENC_B / ENC_HW / ENC_STEPS override.
+fraction of the dense bf16 MFMA peak.  ENC_B / ENC_HW / ENC_STEPS override; ENC_GRAPH=0 launches
+the step eagerly, ENC_FWD=0 leaves out the forward-only timing.
 """
 import json
 import os
@@ -35,12 +36,13 @@ def main():
     torch.cuda.synchronize()
     # forward only
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fwd_steps = steps if os.environ.get("ENC_FWD", "1") != "0" else 0     # ENC_FWD=0: whole steps only (counter runs)
     e0.record()
-    for _ in range(steps):
+    for _ in range(fwd_steps):
         model.forward()
     e1.record()
     torch.cuda.synchronize()
-    fwd_ms = e0.elapsed_time(e1) / steps
+    fwd_ms = e0.elapsed_time(e1) / max(fwd_steps, 1)
     t0 = time.perf_counter()
     e0.record()
     for _ in range(steps):
@@ -54,7 +56,7 @@ def main():
         "workload": "encoder train step, batch %d, %dx%dx4, bf16 operands / f32 accumulate" % (B, HW, HW),
         "images_per_s": B / (step_ms * 1e-3), "step_ms": step_ms, "step_wall_ms": wall_ms, "forward_ms": fwd_ms,
         "tflops_step": f_all / 1e12, "achieved_tflops": f_all / 1e12 / (step_ms * 1e-3),
-        "forward_achieved_tflops": f_fwd / 1e12 / (fwd_ms * 1e-3),
+        "forward_achieved_tflops": f_fwd / 1e12 / (fwd_ms * 1e-3) if fwd_steps else None,
         "mfma_peak_tflops": MFMA_BF16_PEAK_TFLOPS,
         "mfma_frac": f_all / 1e12 / (step_ms * 1e-3) / MFMA_BF16_PEAK_TFLOPS,
         "hip_graph": os.environ.get("ENC_GRAPH", "1") != "0", "loss": float(model.loss), "hbm_gb_allocated": torch.cuda.max_memory_allocated() / 1e9}))
