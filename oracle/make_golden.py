@@ -33,7 +33,32 @@ REF = os.environ.get("SLAM_REFERENCE", "/root/reference")
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
+# sha256 of the text each extraction yields (after blanking): the fixed line ranges are only meaningful for the
+# reference revision they were chosen on, so anything else is refused instead of executed
+EXPECTED_SHA256 = {
+    "slam/preprocess/test_import.py": "251722b335ba6850f7a06c04749bc06b2ece43bd2d71c7ccfc314b1d3053b96d",
+    "slam/network/model_input.py": "2a674d00ad516444cbdf16ae4f587482f192eb6c1d07abb13ad7dd4a7027bea0",
+    "slam/preprocess/import_data.py": "5797882fd569341459d799c2969f4ee0940428792c5b8a7fd21282b2716c6f92",
+}
+
+
+class _PathOnly(object):
+    """What the extracted functions use of `os`: os.path.join, nothing else."""
+
+    class path(object):
+        join = staticmethod(os.path.join)
+
+
 def _load_ranges(relpath, ranges, blank=()):
+    code = _extract_ranges(relpath, ranges, blank)
+    digest = hashlib.sha256(code.encode()).hexdigest()
+    if digest != EXPECTED_SHA256[relpath]:
+        raise SystemExit("%s: the extracted line ranges hash to %s, not to the pinned %s: the reference differs from "
+                         "the revision these ranges were chosen on; nothing was executed" % (relpath, digest, EXPECTED_SHA256[relpath]))
+    return code
+
+
+def _extract_ranges(relpath, ranges, blank=()):
     with open(os.path.join(REF, relpath)) as f:
         lines = f.read().split("\n")
     for ln in blank:
@@ -57,7 +82,7 @@ class _FakeMisc(object):
 
 def load_test_import():
     import bisect
-    ns = {"np": np, "bisect": bisect, "os": os, "misc": _FakeMisc}
+    ns = {"np": np, "bisect": bisect, "os": _PathOnly, "misc": _FakeMisc}
     code = _load_ranges("slam/preprocess/test_import.py",
                         [(14, 15), (18, 110), (148, 246), (255, 263)], blank=(215,))
     exec(compile(code, "<reference:test_import>", "exec"), ns)

@@ -29,6 +29,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_PITCH = 72;   // 64 bf16 of payload + 8 of padding per row (144 B)
 
+// Zero fill as an ordinary kernel (16-byte stores, the last bytes two at a time).  The accumulators that the
+// kernels below add into with atomics are cleared with this instead of hipMemsetAsync: inside a captured
+// HIP graph a memset becomes a node of its own kind, and a replayed training step (some fifty of them)
+// gave wrong sums now and then, while the same step made of kernel nodes alone replays correctly.
+__global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p, size_t n16, uint16_t* __restrict__ tail, int ntail) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
+static hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if ((reinterpret_cast<uintptr_t>(ptr) & 15) || (bytes & 1)) return hipMemsetAsync(ptr, 0, bytes, s);
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)((bytes % 16) / 2);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)ptr, n16,
+                     (uint16_t*)((char*)ptr + n16 * 16), ntail);
+  return hipGetLastError();
+}
+
 // Per-column sum and sum of squares of one wave's 32-column slice of an output tile, from the
 // values as they are stored (rounded to bfloat16): lanes l and l + 32 hold the same column,
 // lanes 0..31 write {sum, sum of squares} of column n to part[n] and part[N + n].
@@ -230,174 +253,13 @@ igemm_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16*
 // 3x3 convolution (or data gradient) by filter row, for the layers with many pixels and few
 // channels, where the per-tap kernel above spends its time staging: a K-step covers the three
 // taps of one filter row and 64 channels.  The pixel tile is staged ONCE per step with one
-// extra pixel on either side (130 rows: pixels m0 - 1 .. m0 + 128 shifted by dy image rows) and
-// the three taps read it at row offsets 0, 1, 2; whether a tap of a pixel lies inside the image
-// is a per-lane bit (a fragment row IS a pixel), applied to the fragment in registers, so the
-// staged rows need no masks, only addresses clamped into the tensor.  Against the per-tap
-// kernel: 43 % (BN = 64) / 31 % (BN = 128) less staging traffic and three times the MFMAs per
-// barrier pair.  bfloat16 output, optional statistics records as above.  Used for 64-wide
-// outputs (BN = 64), where it measures 4-14 % faster; 128-wide tiles gain nothing.
-// ---------------------------------------------------------------------------
-template <int BN>
-__global__ void __launch_bounds__(256, 2)
-igemm_row3_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
-                       int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
-                       float* __restrict__ stat_part, int m_tile0) {
-  constexpr int BM = 128, AR = BM + 2;
-  constexpr int NT = BN / 64;
-  constexpr int NBV = 3 * BN / 32;            // 16-byte B loads per thread and step
-  __shared__ __attribute__((aligned(16))) bf16 As[AR * LDS_PITCH];
-  __shared__ __attribute__((aligned(16))) bf16 Bs[3 * BN * LDS_PITCH];
-
-  const int per_xcd = (total_tiles + 7) >> 3;
-  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if (work >= total_tiles) return;
-  const int m0 = (m_tile0 + work / n_tiles) * BM, n0 = (work % n_tiles) * BN;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int Ktot = 9 * C;
-
-  // A loader: thread -> staged row tid >> 1 (pixel m0 - 1 + row), 64-byte half tid & 1; threads
-  // 0..15 also fetch one 16-byte chunk of the two extra rows 128, 129
-  const int a_row = tid >> 1, a_half = tid & 1;
-  const int h_row = BM + (tid >> 3), h_chunk = tid & 7;
-  const bool has_halo = tid < 16;
-  // B loader: chunk id = tid + 256 v -> tap e, row n, 16-byte chunk
-  const bf16* b_src[NBV];
-  int b_dst[NBV];
-#pragma unroll
-  for (int v = 0; v < NBV; ++v) {
-    const int id = tid + 256 * v, e = id / (BN * 8), rem = id - e * (BN * 8), n = rem >> 3, ch = rem & 7;
-    b_src[v] = Bw + (long long)(n0 + n) * Ktot + e * C + ch * 8;
-    b_dst[v] = (e * BN + n) * LDS_PITCH + ch * 8;
-  }
-
-  // validity of the nine taps of this lane's two fragment rows (pixels)
-  unsigned int fm[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
-    unsigned int mask = 0u;
-    if (m < M) {
-      const int rem = m % (H * W);
-      const int y = rem / W, x = rem - y * W;
-#pragma unroll
-      for (int t = 0; t < 9; ++t)
-        if ((unsigned)(y + t / 3 - 1) < (unsigned)H && (unsigned)(x + t % 3 - 1) < (unsigned)W) mask |= 1u << t;
-    }
-    fm[i] = mask;
-  }
-
-  f32x16 acc[2][NT];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  const int chunks = C / 64, ksteps = 3 * chunks;
-  uint4 ra0, ra1, ra2, ra3, rah, rb[NBV];
-  int g = 0, c0 = 0;     // filter row and channel chunk of the loads in flight
-  rah = make_uint4(0u, 0u, 0u, 0u);
-  const uint32_t b_keep = n0 < N ? 0xffffffffu : 0u;   // always set; the masked copy keeps the staged values in registers
-
-#define SLAMHIP_ROW3_ISSUE()                                                                     \
-  {                                                                                              \
-    const int dy = (flip ? 2 - g : g) - 1;                                                       \
-    long long q = (long long)m0 - 1 + a_row + (long long)dy * W;                                 \
-    q = q < 0 ? 0 : (q > M - 1 ? M - 1 : q);                                                     \
-    const uint4* src = reinterpret_cast<const uint4*>(A + q * C + c0 + a_half * 32);             \
-    ra0 = src[0]; ra1 = src[1]; ra2 = src[2]; ra3 = src[3];                                      \
-    if (has_halo) {                                                                              \
-      long long qh = (long long)m0 - 1 + h_row + (long long)dy * W;                              \
-      qh = qh < 0 ? 0 : (qh > M - 1 ? M - 1 : qh);                                               \
-      rah = *reinterpret_cast<const uint4*>(A + qh * C + c0 + h_chunk * 8);                      \
-    }                                                                                            \
-    _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
-      rb[v] = *reinterpret_cast<const uint4*>(b_src[v] + g * 3 * C + c0);                        \
-    c0 += 64;                                                                                    \
-    if (c0 == C) { c0 = 0; ++g; }                                                                \
-  }
-
-  int g_cur = 0, c_cur = 0;   // position of the step being computed
-  SLAMHIP_ROW3_ISSUE();
-  for (int s = 0; s < ksteps; ++s) {
-    __syncthreads();   // the previous step's fragments have been read
-    {
-      uint4* dst = reinterpret_cast<uint4*>(&As[a_row * LDS_PITCH + a_half * 32]);
-      dst[0] = ra0; dst[1] = ra1; dst[2] = ra2; dst[3] = ra3;
-      if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah;
-    }
-#pragma unroll
-    for (int v = 0; v < NBV; ++v) *reinterpret_cast<uint4*>(&Bs[b_dst[v]]) = and4(rb[v], b_keep);
-    __syncthreads();
-    if (s + 1 < ksteps) SLAMHIP_ROW3_ISSUE();   // in flight while the matrix cores work
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-      const int t = flip ? 8 - (g_cur * 3 + e) : g_cur * 3 + e;     // geometric tap of weight slot (g_cur, e)
-      const int shift = flip ? 2 - e : e;                           // staged row = pixel row + 1 + dx
-      uint32_t keep[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) keep[i] = ((fm[i] >> t) & 1u) ? 0xffffffffu : 0u;
-#pragma unroll
-      for (int kk = 0; kk < 64; kk += 16) {
-        bf16x8 af[2], bfr[NT];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 raw = *reinterpret_cast<const uint4*>(
-              &As[(wm * 64 + i * 32 + (lane & 31) + shift) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-          af[i] = __builtin_bit_cast(bf16x8, and4(raw, keep[i]));
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          bfr[j] = *reinterpret_cast<const bf16x8*>(
-              &Bs[(e * BN + wn * (BN / 2) + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-      }
-    }
-    c_cur += 64;
-    if (c_cur == C) { c_cur = 0; ++g_cur; }
-  }
-#undef SLAMHIP_ROW3_ISSUE
-
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-        if (m < M && n < N) out_bf16[(long long)m * N + n] = (bf16)acc[i][j][r];
-      }
-  if (stat_part) {
-    float* part = stat_part + ((long long)(work / n_tiles) * 2 + wm) * 2 * N;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      float sm = 0.f, sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float v = (float)(bf16)acc[i][j][r];
-          sm += v;
-          sq = __builtin_fmaf(v, v, sq);
-        }
-      store_column_stats(sm, sq, part, n0 + wn * (BN / 2) + j * 32 + (lane & 31), N, lane);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The filter-row kernel with 256 x 64 tiles: four waves stacked along the pixels, 64 x 64
-// outputs each (two A and two B fragments feed four MFMAs: 1 KB of LDS reads per MFMA against
-// 1.5 KB with the 64 x 32 wave tiles above, which bound the 64-channel layers).  One record of
-// column statistics per wave, i.e. two per 128 pixel rows as the other kernels leave.
+// extra pixel on either side (pixels m0 - 1 .. m0 + 256 shifted by dy image rows) and the three
+// taps read it at row offsets 0, 1, 2; whether a tap of a pixel lies inside the image is a
+// per-lane bit (a fragment row IS a pixel), applied to the fragment in registers, so the staged
+// rows need no masks, only addresses clamped into the tensor.  256 x 64 tiles: four waves
+// stacked along the pixels, 64 x 64 outputs each (two A and two B fragments feed four MFMAs:
+// 1 KB of LDS reads per MFMA, which bounds the 64-channel layers).  bfloat16 output; one record
+// of column statistics per wave, i.e. two per 128 pixel rows as the other kernels leave.
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
@@ -585,7 +447,7 @@ __device__ __attribute__((aligned(256))) uint4 g_zero_line[16];   // never writt
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
 
-template <int TAPS, bool PINGPONG>
+template <int TAPS>
 __global__ void __launch_bounds__(512)
 igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
                      int N, int C, int H, int W, int flip, int n_tiles, int total_tiles,
@@ -698,7 +560,7 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
     if (c0 == C) { c0 = 0; ++tap; } \
   }
 
-  if constexpr (PINGPONG) {
+  {
     // The two wave rows (wm = 0 / 1, one wave of each per SIMD) run half a phase apart: while one
     // row's sixteen MFMAs of a phase occupy the matrix cores, the other row reads its next
     // fragments from LDS and, in the first phase of a tile, issues its share of the next tile's
@@ -771,30 +633,6 @@ igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf
 #undef SLAMHIP_PP_LOAD_A
 #undef SLAMHIP_PP_LOAD_B
 #undef SLAMHIP_PP_MFMA2
-  } else {
-  SLAMHIP_IGEMM256_ISSUE(0);
-  for (int s = 0; s < ksteps; ++s) {
-    // the only DMA loads in flight are this step's: once they have landed and every wave has
-    // passed the barrier, the tile is complete and the other buffer is no longer being read
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (s + 1 < ksteps) SLAMHIP_IGEMM256_ISSUE((s + 1) & 1);
-    const unsigned char* a_tile = lds + (s & 1) * 2 * TILE_BYTES;
-    const unsigned char* b_tile = a_tile + TILE_BYTES;
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int chunk = ((kk * 2 + qh) ^ swz) << 4;
-      bf16x8 af[4], bfr[2];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(a_tile + a_off[i] + chunk);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(b_tile + b_off[j] + chunk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-  }
   }
 #undef SLAMHIP_IGEMM256_ISSUE
 #undef SLAMHIP_IGEMM256_PART
@@ -2113,7 +1951,7 @@ static unsigned int channel_stride_grid(long long total8, int C) {
 // rows are strided over the grid: enough blocks to fill the chip, at least ~8 rows per row lane
 static unsigned int reduce_grid(long long P, int C) {
   const int rlanes = 256 / (C / 8);
-  static const long long cap = [] { const char* e = getenv("SLAMHIP_REDUCE_BLOCKS"); return e ? atoll(e) : 1024LL; }();
+  constexpr long long cap = 1024;
   // every block ends in 2C float atomics on the same addresses: beyond ~1024 blocks their
   // serialisation costs more than the extra parallelism brings
   long long g = (P + 8LL * rlanes - 1) / (8LL * rlanes);
@@ -2126,7 +1964,7 @@ static bool use_igemm256(long long M, int N, const void* out_bf16, const float* 
   if (mode == 0 || N % 256 != 0 || !out_bf16 || out_f32) return false;
   // one 256 x 256 workgroup per compute unit: worth it from about three quarters of the chip
   // (196 tiles of a 14 x 14 x 512 layer at batch 128: 147 us against 178 us with 128-row tiles)
-  static const int min_tiles = [] { const char* e = getenv("SLAMHIP_IGEMM256_MIN_TILES"); return e ? atoi(e) : 192; }();
+  constexpr int min_tiles = 192;
   return mode == 2 || (M + 255) / 256 * (N / 256) >= min_tiles;     // 2: always (tests)
 }
 
@@ -2135,13 +1973,8 @@ static void launch_igemm256(const void* a, const void* b, void* out_bf16, long l
                             int flip, hipStream_t s, float* stat_part, int m_tile0 = 0, int m_tiles = -1) {
   if (m_tiles < 0) m_tiles = (int)((M + 255) / 256);
   const int n_tiles = N / 256, total = m_tiles * n_tiles;
-  static const bool pingpong = [] { const char* e = getenv("SLAMHIP_IGEMM256_PINGPONG"); return e ? atoi(e) != 0 : true; }();
-  if (pingpong)
-    hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS, true>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
-                       (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
-  else
-    hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS, false>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
-                       (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
+  hipLaunchKernelGGL((igemm256_bf16_kernel<TAPS>), dim3((total + 7) / 8 * 8), dim3(512), 0, s, (const bf16*)a,
+                     (const bf16*)b, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, m_tile0);
 }
 
 template <int TAPS, int BN>
@@ -2174,52 +2007,35 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
         n = 256;
       return n;
     }();
-    static const int hybrid = [] { const char* e = getenv("SLAMHIP_IGEMM256_HYBRID"); return e ? atoi(e) : 1; }();
     const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 256;
     const long long total = (long long)m_tiles * n_tiles;
     const long long rem = total % cus;
     int m_big = m_tiles;
-    if (hybrid && total > cus && rem != 0 && rem * 4 < cus) m_big = (int)((total - rem) / n_tiles);
+    if (total > cus && rem != 0 && rem * 4 < cus) m_big = (int)((total - rem) / n_tiles);
     launch_igemm256<9>(act, w_nk, out_bf16, M, N, C, H, W, flip, s, stat_part, 0, m_big);
     long long records = 2LL * m_big;
     if (m_big < m_tiles) {
       // the leftover pixel rows: filter-row kernel (a third of the K-steps, two in flight), which a
       // launch of a few dozen workgroups, bound by the latency of its K-steps, finishes sooner
-      static const int leftover = [] { const char* e = getenv("SLAMHIP_IGEMM256_LEFTOVER"); return e ? atoi(e) : 1; }();
       const int m_small = (int)((M - 256LL * m_big + 127) / 128);
       float* part = stat_part ? stat_part + records * 2 * N : nullptr;
-      if (leftover == 1) {
-        const int m_rest = (m_small + 1) / 2, nt = N / 64, total_rest = m_rest * nt;
-        hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total_rest + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
-                           (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, nt, total_rest, part, m_big);
-      } else {
-        launch_igemm<9, 128>(act, w_nk, out_bf16, nullptr, M, N, C, H, W, flip, s, part, 1, 2 * m_big, m_small);
-      }
+      const int m_rest = (m_small + 1) / 2, nt = N / 64, total_rest = m_rest * nt;
+      hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total_rest + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
+                         (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, nt, total_rest, part, m_big);
       records += 2LL * m_small;
     }
     return records;
   }
-  // many pixels, few channels, 64-wide output (bfloat16 only): one K-step per filter row
-  // (SLAMHIP_IGEMM_ROW3: 0 off, 1 the 128 x 64 tiles, 2 the 256 x 64 tiles)
-  static const int row3 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3"); return e ? atoi(e) : 2; }();
-  // (measured at batch 128: 224 x 224 x 64 -> 64 forward 940 -> 901 us, data gradient 847 -> 800 us;
-  // 112 x 112 x 128 -> 64 data gradient 434 -> 372 us; no gain with 128-wide output tiles; the
-  // 256 x 64 tiles another 4-5 % at 224 x 224 and nothing at 112 x 112)
-  // (128-wide outputs too, as two 64-wide tiles: 405 -> 387 us at 112 x 112 x 64 -> 128, 569 -> 554 us
-  // forward and 567 -> 547 us data gradient at 112 x 112 x 128 -> 128; SLAMHIP_IGEMM_ROW3_N128: 0 off,
-  // 1 from 64 channels only, 2 from 64 and 128 channels, 3 from 256 channels as well: 306 -> 275 us
-  // data gradient at 56 x 56 x 256 -> 128)
-  static const int row3_n128 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3_N128"); return e ? atoi(e) : 3; }();
-  const bool row3_shape = N % 64 == 0 && (N % 128 != 0 || (row3_n128 && row3 == 2 && N == 128 && (C == 64 || (row3_n128 >= 2 && C == 128) || (row3_n128 >= 3 && C == 256))));
-  if (row3 && out_bf16 && !out_f32 && row3_shape && C <= (row3_n128 >= 3 ? 256 : 128) && M >= 128 * 1024) {
-    if (row3 == 2) {   // 256 x 64 tiles, 64 x 64 per wave
-      const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 64, total = m_tiles * n_tiles;
-      hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
-                         (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, 0);
-      return (M + 127) / 128 * 2;
-    }
-    const int m_tiles = (int)((M + 127) / 128), n_tiles = N / 64, total = m_tiles * n_tiles;
-    hipLaunchKernelGGL((igemm_row3_bf16_kernel<64>), dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
+  // many pixels, few channels (bfloat16 output only): one K-step per filter row (SLAMHIP_IGEMM_ROW3=0: off)
+  // (measured at batch 128 against the per-tap kernel: 224 x 224 x 64 -> 64 forward 940 -> 860 us, data
+  // gradient 847 -> 765 us; 112 x 112 x 128 -> 64 data gradient 434 -> 372 us; 128-wide outputs as two
+  // 64-wide tiles: 405 -> 387 us at 112 x 112 x 64 -> 128, 569 -> 554 us forward and 567 -> 547 us data
+  // gradient at 112 x 112 x 128 -> 128, 306 -> 275 us data gradient at 56 x 56 x 256 -> 128)
+  static const bool row3 = [] { const char* e = getenv("SLAMHIP_IGEMM_ROW3"); return e ? atoi(e) != 0 : true; }();
+  const bool row3_shape = N % 64 == 0 && (N % 128 != 0 || (N == 128 && (C == 64 || C == 128 || C == 256)));
+  if (row3 && out_bf16 && !out_f32 && row3_shape && C <= 256 && M >= 128 * 1024) {
+    const int m_tiles = (int)((M + 255) / 256), n_tiles = N / 64, total = m_tiles * n_tiles;
+    hipLaunchKernelGGL(igemm_row3w_bf16_kernel, dim3((total + 7) / 8 * 8), dim3(256), 0, s, (const bf16*)act,
                        (const bf16*)w_nk, (bf16*)out_bf16, (int)M, N, C, H, W, flip, n_tiles, total, stat_part, 0);
     return (M + 127) / 128 * 2;
   }
@@ -2255,7 +2071,7 @@ size_t slamhip_conv_stats_workspace_bytes(long long pixels, int N) {
 
 // sums2c[0..2N) = column sums of the R per-tile records in ws
 static int finish_stats(const float* ws, float* sums2c, long long R, int N, hipStream_t s) {
-  SLAMHIP_HIP(hipMemsetAsync(sums2c, 0, sizeof(float) * 2 * (size_t)N, s));
+  SLAMHIP_HIP(zero_async(sums2c, sizeof(float) * 2 * (size_t)N, s));
   long long slices = (R + 63) / 64;
   if (slices > 512) slices = 512;
   hipLaunchKernelGGL(stat_finish_kernel, dim3((2 * N + 255) / 256, (unsigned)slices), dim3(256), 0, s, ws, sums2c,
@@ -2298,7 +2114,7 @@ int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, flo
     if (splitk > K / 256) splitk = K / 256;      // at least four K-steps per slice
     if (splitk < 1) splitk = 1;
   }
-  if (splitk > 1) SLAMHIP_HIP(hipMemsetAsync(out_f32, 0, sizeof(float) * (size_t)M * N, s));
+  if (splitk > 1) SLAMHIP_HIP(zero_async(out_f32, sizeof(float) * (size_t)M * N, s));
   if (bn == 128) launch_igemm<1, 128>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s, nullptr, splitk);
   else launch_igemm<1, 64>(a_mk, b_nk, out_bf16, out_f32, M, N, K, 1, 1, 0, s, nullptr, splitk);
   SLAMHIP_HIP(hipGetLastError());
@@ -2326,7 +2142,7 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
     if (split < 1) split = 1;
     const long long chunk = (S + split - 1) / split;
     split = (S + chunk - 1) / chunk;
-    SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+    SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
     const long long total3 = tiles3 * split;
     hipLaunchKernelGGL(wgrad_rows64_kernel, dim3((unsigned)((total3 + 7) / 8 * 8)), dim3(256), 0, s, (const bf16*)x,
                        (const bf16*)dy, dw, B, H, W, Cin, Cout, (int)split, (int)total3);
@@ -2348,7 +2164,7 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
       if (split < 1) split = 1;
       const long long chunk = (S + split - 1) / split;
       split = (S + chunk - 1) / chunk;
-      SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+      SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
       const long long total3 = tiles3 * split;
       const dim3 grid3((unsigned)((total3 + 7) / 8 * 8));
       if (TMg == 128)
@@ -2363,10 +2179,7 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   }
   const int TM = Cin % 128 == 0 ? 128 : 64, TN = Cout % 128 == 0 ? 128 : 64;
   const long long tiles = (long long)(Cin / TM) * (Cout / TN) * taps;
-  static const long long target_blocks = [] {
-    const char* e = getenv("SLAMHIP_WGRAD_BLOCKS");     // tuning knob
-    return e ? atoll(e) : 2048LL;
-  }();
+  constexpr long long target_blocks = 2048;
   // at most target_blocks workgroups (two full rounds at four per compute unit: a few more would
   // start a third, nearly empty round), at least 3584 pixels per slice (each slice ends in
   // TM x TN float atomics)
@@ -2379,7 +2192,7 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
     const long long chunk = ((P + splitk - 1) / splitk + 63) / 64 * 64;
     splitk = (P + chunk - 1) / chunk;
   }
-  if (splitk != 1 || P == 0) SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * (size_t)taps * Cin * Cout, s));
+  if (splitk != 1 || P == 0) SLAMHIP_HIP(zero_async(dw, sizeof(float) * (size_t)taps * Cin * Cout, s));
   if (P == 0) return SLAMHIP_OK;
   const long long total = tiles * splitk;
   SLAMHIP_REQUIRE(total < (1LL << 30), SLAMHIP_E_SIZE, "wgrad: too many workgroups");
@@ -2453,7 +2266,7 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
   SLAMHIP_REQUIRE(x && dy && dw && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= 256 && 256 % Cout == 0,
                   SLAMHIP_E_ARG, "conv3x3_small_wgrad: bad argument (Cout must divide 256)");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
   if (B == 0) return SLAMHIP_OK;
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
@@ -2474,7 +2287,7 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
 int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void* stream) {
   SLAMHIP_REQUIRE(z && sums2c && P >= 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG, "channel_stats: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(sums2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(sums2c, sizeof(float) * 2 * (size_t)C, s));
   if (P == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "channel_stats: more than 2048 channels");
@@ -2503,7 +2316,7 @@ int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, cons
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_bwd: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
   hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
   const long long total8 = P * C / 8;
@@ -2522,8 +2335,8 @@ int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* 
   SLAMHIP_REQUIRE(Pl <= 0x7fffffffLL / 64, SLAMHIP_E_SIZE, "bn_relu_bwd_first_layer: too many pixels");
   const int P = (int)Pl, C = 64;
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
-  SLAMHIP_HIP(hipMemsetAsync(dw, 0, sizeof(float) * 9 * 4 * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * 4 * (size_t)C, s));
   hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, P, C, 1.0f / (float)P, eps);
   const int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
@@ -2555,7 +2368,7 @@ int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* su
   const long long P = (long long)B * H * W, PP = P / 4;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_pool_bwd: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(red2c, 0, sizeof(float) * 2 * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
   hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(reduce_grid(PP, C)), dim3(256), 0, s, (const bf16*)dpooled,
                      (const bf16*)z, sums2c, gamma, beta, red2c, PP, H, W, C, 1.0f / (float)P, eps);
   const long long total8 = PP * (C / 8);
@@ -2602,7 +2415,7 @@ int slamhip_maxpool2_bwd(const void* x, const void* y, const void* dy, void* dx,
   SLAMHIP_REQUIRE(x && y && dy && dx && B >= 0 && H >= 2 && W >= 2 && C > 0 && C % 8 == 0, SLAMHIP_E_ARG,
                   "maxpool2_bwd: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  if ((H & 1) || (W & 1)) SLAMHIP_HIP(hipMemsetAsync(dx, 0, 2 * (size_t)B * H * W * C, s));
+  if ((H & 1) || (W & 1)) SLAMHIP_HIP(zero_async(dx, 2 * (size_t)B * H * W * C, s));
   const long long total = (long long)B * (H / 2) * (W / 2) * (C / 8);
   if (total == 0) return SLAMHIP_OK;
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16*)x, (const bf16*)y,
@@ -2687,7 +2500,7 @@ int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias,
                   "bias_relu_bwd: bad argument");
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bias_relu_bwd: too many rows");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)C, s));
+  SLAMHIP_HIP(zero_async(dbias, sizeof(float) * (size_t)C, s));
   if (P == 0) return SLAMHIP_OK;
   hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
                      (const bf16*)y, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,

@@ -740,6 +740,22 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Clears accumulator records with a kernel (a record is 64 bytes, four 16-byte stores): callers may record
+// these entry points in a HIP graph, where a memset becomes a node of its own kind; kernel nodes alone
+// replay in order.
+__global__ void __launch_bounds__(256) clear_records_kernel(uint4* __restrict__ p, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+
+static hipError_t clear_records(void* workspace, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if (!aligned_to(workspace, 16) || bytes % 16) return hipMemsetAsync(workspace, 0, bytes, s);
+  const size_t n16 = bytes / 16;
+  hipLaunchKernelGGL(clear_records_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)workspace, n16);
+  return hipGetLastError();
+}
+
 }  // namespace slamhip
 
 using namespace slamhip;
@@ -756,12 +772,17 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
-  // tile shape: 128 x 32 pixels on four waves by default; SLAMHIP_TILE = "16x16" (two waves), "16x8", "24x12" for tuning
+  // tile shape: 128 x 32 pixels on four waves (tuning builds with -DSLAMHIP_TUNING_TILES also hold 128 x 16
+  // on two or four waves, 128 x 24 and 128 x 32 on two waves, chosen by SLAMHIP_TILE; all measured slower)
+#ifdef SLAMHIP_TUNING_TILES
   static const int tile_cfg = []() {
     const char* e = getenv("SLAMHIP_TILE");
     const std::string v = e ? e : "";
     return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : 0;
   }();
+#else
+  constexpr int tile_cfg = 0;
+#endif
   const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
   FusedArgs a;
   PairAcc* ws = (PairAcc*)workspace;
@@ -804,6 +825,7 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
     else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false>), grid, block, 0, s, a, depth1, rgb1,        \
                             depth2, rgb2, rel4x4, ws, sums, counts);                                               \
   } while (0)
+#ifdef SLAMHIP_TUNING_TILES
   switch (tile_cfg) {
     case 1: SLAMHIP_LAUNCH_FUSED(16, 16); break;
     case 2: SLAMHIP_LAUNCH_FUSED(16, 8); break;
@@ -811,6 +833,9 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
     case 4: SLAMHIP_LAUNCH_FUSED(32, 32); break;
     default: SLAMHIP_LAUNCH_FUSED(32, 16); break;
   }
+#else
+  SLAMHIP_LAUNCH_FUSED(32, 16);
+#endif
 #undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
@@ -846,7 +871,7 @@ int slamhip_pair_loss_fused(const uint16_t* depth1, const uint8_t* rgb1, const u
 int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, void* stream) {
   SLAMHIP_REQUIRE(workspace || workspace_bytes == 0, SLAMHIP_E_ARG, "pair_loss_reset_workspace: null workspace");
   if (workspace_bytes == 0) return SLAMHIP_OK;
-  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, workspace_bytes, (hipStream_t)stream));
+  SLAMHIP_HIP(clear_records(workspace, workspace_bytes, (hipStream_t)stream));
   return SLAMHIP_OK;
 }
 
@@ -879,7 +904,7 @@ int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, 
   }
   hipStream_t s = (hipStream_t)stream;
   // the array keeps whatever the last call (possibly an interrupted one) left: clear the records of this call
-  SLAMHIP_HIP(hipMemsetAsync(ptr, 0, sizeof(PairAcc) * (size_t)B * (size_t)k, s));
+  SLAMHIP_HIP(clear_records(ptr, sizeof(PairAcc) * (size_t)B * (size_t)k, s));
   return launch_pair_loss("pair_loss_fused_static", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W,
                           sums, counts, ptr, s);
 }

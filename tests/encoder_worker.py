@@ -97,7 +97,7 @@ def nccl1(out):
     from slam_amd import distributed as dp
     from slam_amd.network.cnn_model import VGG16Model
 
-    def run(steps):
+    def make():
         dev = torch.device("cuda:0")
         g = torch.Generator().manual_seed(3)
         x = torch.randn(4, 64, 64, 4, generator=g).to(dev)
@@ -106,17 +106,29 @@ def nccl1(out):
         model.add_loss(torch.eye(6, device=dev), torch.randn(4, 6, generator=g).to(dev))
         step = model.add_optimizer(optimizer='AdamOptimizer')
         model._optimizer.learning_rate = 1e-4
-        losses = [float(step()) for _ in range(steps)]
-        torch.cuda.synchronize()
-        return losses, model.flat_params.cpu().numpy(), model.flat_grads.cpu().numpy()
+        return model, step
 
     assert dp.initialised() and dp.world_size() == 1
-    l_dp, p_dp, g_dp = run(1)            # backward_with_allreduce: two bucketed all-reduces over RCCL
-    l_dp3, _, _ = run(3)
+    # the gradients of one forward pass: through backward_with_allreduce() (two bucketed all-reduces over
+    # RCCL) and through backward() alone, from the same activations
+    model, step = make()
+    model.forward()
+    model.compute_loss(with_gradient=True)
+    model.backward_with_allreduce()
+    torch.cuda.synchronize()
+    g_dp = model.flat_grads.cpu().numpy()
+    model.backward()
+    torch.cuda.synchronize()
+    g_1 = model.flat_grads.cpu().numpy()
+    # whole training steps under the group
+    model, step = make()
+    l_dp = [float(step()) for _ in range(3)]
+    p_dp = model.flat_params.cpu().numpy()
     dist.destroy_process_group()
     assert not dp.initialised()
-    l_1, p_1, g_1 = run(1)               # the same step without a process group
-    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), p_dp=p_dp, p_1=p_1, g_dp=g_dp, g_1=g_1, l_dp3=np.array(l_dp3))
+    model, step = make()
+    l_1 = [float(step()) for _ in range(3)]
+    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), g_dp=g_dp, g_1=g_1, p_dp=p_dp)
 
 
 if __name__ == "__main__":

@@ -43,3 +43,14 @@ for i in range(1, 12):
     prev = s[:, i]
 life = (s[:, 11] - s[:, 0]) / 2100.0
 print("lifetime           median %.2f us  mean %.2f  p90 %.2f" % (np.median(life), life.mean(), np.percentile(life, 90)))
+# residency over the launch (real-time clock, 10 ns ticks): workgroups resident per 4 us bin, and the mean
+# lifetime of the workgroups that started in that bin
+r0 = s[:, 13].min()
+st, en = (s[:, 13] - r0) / 100.0, (s[:, 14] - r0) / 100.0
+span = en.max()
+print("bin start us | resident workgroups (mean) | started | mean lifetime of those us")
+for a in np.arange(0.0, span, 4.0):
+    b = a + 4.0
+    resident = np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / 4.0
+    started = (st >= a) & (st < b)
+    print("%8.0f | %8.1f | %5d | %s" % (a, resident, started.sum(), "%.2f" % (en[started] - st[started]).mean() if started.any() else "-"))
