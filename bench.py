@@ -95,11 +95,18 @@ def counters_for(json_path, source_path):
     return rec if rec.get("source_sha256") == sha else None
 
 
-def train_loop(fp, buf, K, factor, steps):
-    """prep -> encoder step -> frame-pair losses on the same B pairs; per-stage split from events."""
+def train_loop(fp, buf, K, factor, steps, world=1, dp=None):
+    """prep -> encoder step -> frame-pair losses on the same pairs; per-stage split from events.
+    One GPU: 64 pairs = 128 frames per step, the encoder step replayed from a HIP graph.  Several ranks
+    (BASELINE configs[3]: batch 512 over 8 GPUs): 32 pairs = 64 frames per rank and step, the eager
+    data-parallel step with the gradient all-reduce over RCCL; barrier on both sides, maximum over ranks."""
     from slam_amd.network import prep
     from slam_amd.network.cnn_model import VGG16Model
     d1, c1, d2, c2, rel = buf
+    dp = world > 1 if dp is None else dp     # (dp=True with world == 1: the data-parallel path under a group of one, for tests)
+    if dp:
+        half = d1.shape[0] // 2
+        d1, c1, d2, c2, rel = (t[:half].contiguous() for t in (d1, c1, d2, c2, rel))
     B = d1.shape[0]
     dev = d1.device
     rgb = torch.cat([c1, c2[:, 0]], 0).contiguous()          # 2 B raw frames
@@ -110,7 +117,11 @@ def train_loop(fp, buf, K, factor, steps):
     model.add_loss(torch.eye(6, device=dev), torch.zeros(2 * B, 6, device=dev))
     model.add_optimizer(optimizer='AdamOptimizer')
     model._optimizer.learning_rate = 1e-5
-    step = model.capture_train_step(warmup=2)
+    if not dp:
+        step = model.capture_train_step(warmup=2)
+    else:
+        step = model.train_step
+        step(), step()
     plan = fp.PairLossPlan(d1, c1, d2, c2, rel, K, factor)
 
     def one(ev=None):
@@ -124,17 +135,30 @@ def train_loop(fp, buf, K, factor, steps):
     for _ in range(2):
         one()
     torch.cuda.synchronize()
+    if dp:
+        import torch.distributed as dist
+        dist.barrier()
+        torch.cuda.synchronize()
     evs = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(steps)]
     t0 = time.perf_counter()
     for e in evs:
         e[0].record()
         one(e)
     torch.cuda.synchronize()
+    if dp:
+        dist.barrier()
+        torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    if dp:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
     split = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in evs]).mean(0)
-    return {"workload": "per step: slamhip_prep_rgbd of %d raw 640x480 frames -> encoder training step (batch %d, "
-                        "HIP graph) -> fused frame-pair kernel on the %d pairs they form" % (2 * B, 2 * B, B),
-            "pairs_per_s": B * steps / el, "step_ms": el / steps * 1e3, "steps": steps,
+    return {"workload": "per step and GPU: slamhip_prep_rgbd of %d raw 640x480 frames -> encoder training step (batch %d, "
+                        "%s) -> fused frame-pair kernel on the %d pairs they form"
+                        % (2 * B, 2 * B, "HIP graph" if not dp else "eager, gradient all-reduce over %d ranks" % world, B),
+            "pairs_per_s": world * B * steps / el, "step_ms": el / steps * 1e3, "steps": steps, "n_gpus": world,
+            "global_encoder_batch": world * 2 * B,
             "stage_ms": {"prep": float(split[0]), "encoder_step": float(split[1]), "pair_loss": float(split[2])},
             "loss_finite": bool(torch.isfinite(model.loss).all())}
 
@@ -262,9 +286,9 @@ def main():
     # input preparation of the 2 B frames (slamhip_prep_rgbd) -> encoder training step on them -> fused
     # frame-pair kernel on the B pairs.
     train = None
-    if a.train_steps > 0 and world == 1 and (k, H, W) == (1, 480, 640):
+    if a.train_steps > 0 and (k, H, W) == (1, 480, 640) and B % 2 == 0:
         try:
-            train = train_loop(fp, bufs[0], K, a.factor, a.train_steps)
+            train = train_loop(fp, bufs[0], K, a.factor, a.train_steps, world)
         except Exception as e:
             train = {"error": "%s: %s" % (type(e).__name__, e)}
 

@@ -316,6 +316,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
   // the first neighbour's pose is asked for before anything else: the window prediction waits for it
   Pose p_next = load_pose(rel + 16 * ((long long)b * k));
+#ifdef SLAMHIP_EXP_POSEWAIT   // diagnostic: how long the pose takes by itself
+  asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(p_next.t0), "s"(p_next.r00));
+  SLAMHIP_STAMP(15);
+#endif
 
   // ---- anchor pixels of this lane: raw depth and the eight bytes that hold the colour, read once per tile;
   // nothing here waits for the loads: they stay in flight behind the window prediction and the staging ----

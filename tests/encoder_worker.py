@@ -3,6 +3,7 @@ process, and a process group is set up before the first GPU call, so both need a
 
   python tests/encoder_worker.py fullsize OUT.npz      forward + loss + backward at batch 128, 224x224, full width
   python tests/encoder_worker.py layers OUT.npz        every layer's kernels on seeded inputs of its real shape, one layer at a time
+  python tests/encoder_worker.py benchdp OUT.npz       bench.py's multi-rank training-loop leg under an RCCL group of one
   python tests/encoder_worker.py nccl1 OUT.npz         train_step() under an RCCL process group of one
 """
 import os
@@ -131,5 +132,29 @@ def nccl1(out):
     np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), g_dp=g_dp, g_1=g_1, p_dp=p_dp)
 
 
+def benchdp(out):
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", os.environ.get("WORKER_PORT", "29534"))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    import bench
+    from slam_amd import frame_pairs as fp
+    from slam_amd.utils import synthetic as syn
+    B, H, W = 8, 480, 640
+    K = fp.intrinsics(1)
+    gt = torch.from_numpy(syn.pose_pairs(B, seed=3)).cuda()
+    rel = fp.relative_pose(gt[:, 0].contiguous(), gt[:, 1].contiguous()).reshape(B, 1, 4, 4)
+    buf = [torch.from_numpy(syn.depth_frames(B, H, W, seed=1, kind="plane")).cuda(),
+           torch.from_numpy(syn.rgb_frames(B, H, W, seed=1)).cuda(),
+           torch.from_numpy(syn.depth_frames(B, H, W, seed=2, kind="plane")).cuda().reshape(B, 1, H, W),
+           torch.from_numpy(syn.rgb_frames(B, H, W, seed=2)).cuda().reshape(B, 1, H, W, 3), rel]
+    r = bench.train_loop(fp, buf, K, 1.0, 2, world=1, dp=True)
+    dist.destroy_process_group()
+    np.savez(out, pairs_per_s=r["pairs_per_s"], loss_finite=r["loss_finite"], batch=r["global_encoder_batch"],
+             stages=np.array(list(r["stage_ms"].values())))
+
+
 if __name__ == "__main__":
-    {"fullsize": fullsize, "layers": layers, "nccl1": nccl1}[sys.argv[1]](sys.argv[2])
+    {"fullsize": fullsize, "layers": layers, "nccl1": nccl1, "benchdp": benchdp}[sys.argv[1]](sys.argv[2])

@@ -125,3 +125,12 @@ def test_train_step_under_rccl_group_of_one(tmp_path):
     # channel statistics moves it in the fourth digit); training proceeds
     np.testing.assert_allclose(r["l_dp"][0], r["l_1"][0], rtol=5e-3)
     assert np.isfinite(r["l_dp"]).all() and r["l_dp"][-1] < r["l_dp"][0] and np.isfinite(r["p_dp"]).all()
+
+
+def test_bench_training_loop_leg_for_several_ranks(tmp_path):
+    """bench.py's `train_step` leg as the ranks of a multi-GPU run execute it (eager data-parallel step,
+    barriers, maximum over ranks), here under an RCCL group of one on 4 pairs."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    r = _worker("benchdp", str(tmp_path / "benchdp.npz"), {"WORKER_PORT": str(29900 + os.getpid() % 90)})
+    assert bool(r["loss_finite"]) and float(r["pairs_per_s"]) > 0 and int(r["batch"]) == 8
+    assert (r["stages"] > 0).all()

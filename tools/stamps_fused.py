@@ -36,6 +36,9 @@ t0 = s[:, 0].min()
 print("workgroups stamped: %d; kernel span %.1f us (ticks are shader cycles; 2.1 GHz assumed)" % (len(s), (s[:, 11].max() - t0) / 2100.0))
 d = (s[:, 12] - s[:, 1]) / 2100.0
 print("%-18s median %.2f us  mean %.2f  p90 %.2f (after the anchor loads were issued)" % ("pose arrived", np.median(d), d.mean(), np.percentile(d, 90)))
+if (s[:, 15] != 0).any():
+    d = (s[:, 15] - s[:, 0]) / 2100.0
+    print("%-18s median %.2f us  mean %.2f  p90 %.2f (pose waited for right after its load, before the anchors)" % ("pose alone", np.median(d), d.mean(), np.percentile(d, 90)))
 prev = s[:, 0]
 for i in range(1, 12):
     d = (s[:, i] - prev) / 2100.0
