@@ -38,8 +38,8 @@ namespace slamhip {
 // per-lane constant.  Per neighbour frame:
 //   A  wave 0 predicts the window of the neighbour frame the tile's taps fall into
 //      (the tile's corners projected in float32 at the nearest and farthest depth);
-//   B  all waves stage that window into LDS as 8-byte cells {half(1024+R) | half(1024+G),
-//      half(1024+B) | raw depth} with 16-byte / 8-byte global loads;
+//   B  all waves stage that window into LDS as 8-byte cells {R | G << 16, B | raw depth << 16}
+//      (colour bytes read as binary16 subnormals) with 16-byte / 8-byte global loads;
 //   C  phase 1 and phase 2 above; a tap outside the window (large parallax, a window
 //      cut at WIN_PITCH x WIN_ROWS) is gathered straight from global memory in phase 2,
 //      so the prediction never affects results.
@@ -112,21 +112,22 @@ __device__ __forceinline__ unsigned int wave_isum63(unsigned int x) {
 }
 
 // LDS cell of one neighbour-frame pixel (8 bytes):
-//   x = half(1024 + R) | half(1024 + G) << 16,  y = half(1024 + B) | raw_depth << 16
-// binary16 has ulp 1 on [1024, 2048), so half(1024 + n) is the bit pattern
-// 0x6400 | n for a byte n: building a cell is byte shuffling, no conversion.
-// Colour differences (exact packed-half subtractions) are free of the bias and
-// each interpolation step is one mixed-precision fma; the bias rides along in
-// the interpolated value and cancels against the equally biased anchor colour.
+//   x = R | G << 16,  y = B | raw_depth << 16
+// A byte n in the low bits of a binary16 is the subnormal n * 2^-24: building a cell is byte
+// shuffling, no conversion and no exponent to put in.  The colour arithmetic runs on these scaled
+// values (subnormals are kept: the kernels run with denormal mode 3 for 16-, 32- and 64-bit operands):
+// colour differences are exact packed-half subtractions, each interpolation step is one
+// mixed-precision fma, the anchor colour is scaled the same way, and the two photometric sums
+// are multiplied by 2^24 and 2^48 once per wave and neighbour.
 typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
 typedef unsigned short ushort2_t __attribute__((ext_vector_type(2)));
-constexpr unsigned int HALF_BIAS2 = 0x64006400u;   // two halves of 1024.0
+constexpr float COLOUR_UNSCALE = 0x1p24f;   // a colour byte read as binary16 is the byte times 2^-24
 
 __device__ __forceinline__ half2_t as_half2(unsigned int v) { return __builtin_bit_cast(half2_t, v); }
 __device__ __forceinline__ uint2 make_cell(unsigned int r, unsigned int g, unsigned int b, unsigned int depth) {
   uint2 c;
-  c.x = HALF_BIAS2 | r | (g << 16);
-  c.y = 0x6400u | b | (depth << 16);
+  c.x = r | (g << 16);
+  c.y = b | (depth << 16);
   return c;
 }
 __device__ __forceinline__ unsigned int pk_min_u16(unsigned int a, unsigned int b) {
@@ -191,8 +192,8 @@ __device__ __forceinline__ bool taps_nonzero(const Cells& t) {  // all four raw 
 // in the oracle (top row, bottom row, then vertical) with fused multiply-adds; the
 // deviation from the unfused float32 oracle is a few 1e-7.  Colour differences are exact
 // in binary16; each horizontal lerp is one mixed-precision fma.  a_rg / a_b: the anchor's
-// colour as biased binary16 patterns, half2(1024 + R, 1024 + G) and half(1024 + B) in the
-// low 16 bits.  z2: the transformed depth (float64).  c_geo counts the pixels that also have
+// colour in the cells' form, bytes R | G << 16 and B (binary16 subnormals, the colour times 2^-24);
+// acc.ap and acc.sp therefore collect 2^-24 and 2^-48 of the photometric sums.  z2: the transformed depth (float64).  c_geo counts the pixels that also have
 // four non-zero depth taps.  Runs only on lanes whose pixel warps (warp_valid).
 template <bool UNIT>
 __device__ __forceinline__ void blend_accumulate(Acc& acc, unsigned int& c_geo, const Cells& t, float fu, float fv,
@@ -207,7 +208,7 @@ __device__ __forceinline__ void blend_accumulate(Acc& acc, unsigned int& c_geo, 
   const float wr = __builtin_fmaf(fv, br - tr, tr), wg = __builtin_fmaf(fv, bg - tg, tg);
   const float wb = __builtin_fmaf(fv, bb - tb, tb);
   // anchor - warped (the sign is irrelevant to |r| and r^2): one mixed-precision fma per channel,
-  // the anchor (same bias of 1024 as the cells) read as binary16 in place
+  // the anchor (scaled like the cells) read as binary16 in place
   float rr, rg, rb;
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rr) : "v"(wr), "v"(a_rg));
   asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rg) : "v"(wg), "v"(a_rg));
@@ -466,8 +467,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         const unsigned int sel_rg = 0x0c000c00u | (unsigned int)(br - 4 * kk) | ((unsigned int)(bg - 4 * kk) << 16);
         const unsigned int sel_bd = 0x00000c00u | (unsigned int)(bb & 3) | ((4u + 2u * (i & 1)) << 16) | ((5u + 2u * (i & 1)) << 24);
         uint2 cell;
-        cell.x = __builtin_amdgcn_perm(cw[kk + 1], cw[kk], sel_rg) | HALF_BIAS2;
-        cell.y = __builtin_amdgcn_perm(dw[i >> 1], cw[bb >> 2], sel_bd) | 0x6400u;
+        cell.x = __builtin_amdgcn_perm(cw[kk + 1], cw[kk], sel_rg);
+        cell.y = __builtin_amdgcn_perm(dw[i >> 1], cw[bb >> 2], sel_bd);
 #ifdef SLAMHIP_ABL_LINEAR_STAGE   // timing ablation only: lane-contiguous (conflict-free) but wrong cell positions
         win[(i * 256 + (threadIdx.x & 255)) % (WIN_PITCH * WIN_ROWS)] = cell;
 #else
@@ -627,8 +628,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         if (r + 1 < RPW) nxt = project_row(r + 1);
         if (__builtin_amdgcn_inverse_ballot_w64(cur.m_fast)) {
           const unsigned int argb = a_rgb[r];
-          const unsigned int a_rg = __builtin_amdgcn_perm(0x64u, argb, 0x04010400u);
-          const unsigned int a_b = __builtin_amdgcn_perm(0x64u, argb, 0x0c0c0402u);
+          const unsigned int a_rg = __builtin_amdgcn_perm(0u, argb, 0x0c010c00u);
+          const unsigned int a_b = __builtin_amdgcn_perm(0u, argb, 0x0c0c0c02u);
           blend_accumulate<UNIT>(acc, c_geo, cur.t, cur.fu, cur.fv, inv_factor_f, a_rg, a_b, cur.Z);
         }
         cur = nxt;
@@ -678,8 +679,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
             }
             const uint8_t* cp = c1b + 3 * o;
             const unsigned int rgbx = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
-            const unsigned int a_rg = __builtin_amdgcn_perm(0x64u, rgbx, 0x04010400u);
-            const unsigned int a_b = __builtin_amdgcn_perm(0x64u, rgbx, 0x0c0c0402u);
+            const unsigned int a_rg = __builtin_amdgcn_perm(0u, rgbx, 0x0c010c00u);
+            const unsigned int a_b = __builtin_amdgcn_perm(0u, rgbx, 0x0c0c0c02u);
             blend_accumulate<UNIT>(acc, c_geo, t, fu, fv, inv_factor_f, a_rg, a_b, z2);
           }
         }
@@ -693,7 +694,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     // ---- reduce: DPP within the wave, LDS across the four waves, one atomic each ----
     // (64 lanes adding to one LDS word serialise in the LDS pipe and stall the
     // wave far longer than the 6 DPP steps cost)
-    const float t0 = wave_sum63(acc.ap), t1 = wave_sum63(acc.sp);
+    const float t0 = wave_sum63(acc.ap) * COLOUR_UNSCALE, t1 = wave_sum63(acc.sp) * (COLOUR_UNSCALE * COLOUR_UNSCALE);
     const float t2s = wave_sum63(acc.ag), t3 = wave_sum63(acc.sg);
     const unsigned int n_geo = wave_isum63(c_geo);
     if (lane == 63) {
