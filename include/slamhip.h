@@ -145,7 +145,8 @@ int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, v
  * counterpart in the reference.  Same inputs, outputs and arithmetic, no workspace
  * argument: the accumulator records live in a device array built into the library
  * (SLAMHIP_STATIC_MAX_PAIRS records of 64 bytes on every GPU the library runs on, held
- * until the process ends), which the call clears on `stream` before the launch.  It
+ * until the process ends), which the call clears on `stream` before the launch (with a kernel:
+ * a captured call holds kernel nodes only).  It
  * calls no hipMalloc / hipFree.  B * k beyond SLAMHIP_STATIC_MAX_PAIRS is rejected with
  * SLAMHIP_E_SIZE.  All calls on one GPU share that GPU's array: calls that overlap on
  * one GPU (different streams or threads) race and must be serialised by the caller.  The first call on

@@ -507,7 +507,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
 
     Acc acc = {0.f, 0.f, 0.f, 0.f};
-    unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0;
+    unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_fast = 0;
     unsigned int c_geo = 0u;       // per lane: pixels with four non-zero depth taps (summed over the wave at the end)
     unsigned int rest_bits = 0u;   // bit r: row r of this lane is left to phase 2
 
@@ -599,8 +599,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         unsigned int idx = __umul24(dv, (unsigned int)WIN_PITCH) + du;
         asm("" : "+v"(idx));   // keeps the "* 8" of the cell size a shift: the reads are then known to be 8-byte aligned
         o.t = read_cells(win, __builtin_amdgcn_inverse_ballot_w64(o.m_fast) ? idx : 0u);
-        const unsigned int nf = (unsigned int)__popcll(o.m_fast);
-        n_valid0 += nf; n_inb += nf; n_warp += nf;
+        n_fast += (unsigned int)__popcll(o.m_fast);   // these pixels count for all three masks (added at the end)
         const unsigned long long m_other = m_valid0 & ~o.m_fast;
         if (m_other != 0ull) {
           // Certified pixels outside the window: floor(u) = wx0 + du and floor(v) = wy0 + dv are the
@@ -699,7 +698,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     const unsigned int n_geo = wave_isum63(c_geo);
     if (lane == 63) {
       s_sum[wave][0] = t0; s_sum[wave][1] = t1; s_sum[wave][2] = t2s; s_sum[wave][3] = t3;
-      s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; s_cnt[wave][2] = n_warp; s_cnt[wave][3] = n_geo;
+      s_cnt[wave][0] = n_valid0 + n_fast; s_cnt[wave][1] = n_inb + n_fast; s_cnt[wave][2] = n_warp + n_fast; s_cnt[wave][3] = n_geo;
     }
     __syncthreads();   // also: every gather is done before the next neighbour restages the window
     SLAMHIP_STAMP(10);  // all waves reduced
