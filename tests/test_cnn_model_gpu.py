@@ -407,4 +407,6 @@ def test_graph_replays_stay_finite_with_host_reads_between_steps():
 
     eager, replayed = run(False), run(True)
     assert np.isfinite(replayed).all()
-    np.testing.assert_allclose(replayed[:3], eager[:3], rtol=0.15)
+    # (run-to-run spread of this trajectory, eager against eager: 1 % at the first step, 12 % at the third)
+    np.testing.assert_allclose(replayed[:2], eager[:2], rtol=0.1)
+    np.testing.assert_allclose(replayed[2:4], eager[2:4], rtol=0.35)
