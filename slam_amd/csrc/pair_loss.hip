@@ -263,7 +263,7 @@ struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned
 // waves per SIMD the register allocation must allow: what the LDS windows of TH-row tiles leave room for
 constexpr int fused_waves(int th, int nw) { const int wg = 163840 / (TILE_W + 32) / 8 / win_rows(th); return (wg * nw + 3) / 4 > 8 ? 8 : (wg * nw + 3) / 4; }
 
-template <int TH, int RPW, bool UNIT>
+template <int TH, int RPW, bool UNIT, bool K1>
 __global__ void __launch_bounds__(128 * (TH / RPW), fused_waves(TH, 2 * (TH / RPW)))
 pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
                        const uint16_t* __restrict__ depth2, const uint8_t* __restrict__ rgb2,
@@ -373,10 +373,15 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   unsigned int zmn = 0xffffu, zmx = 0u;
   bool have_range = false;
 
-  for (int j = 0; j < k; ++j) {
+  // (K1: the kernel for a single neighbour per anchor, which holds no pose of a next neighbour in registers)
+  const int n_neighbours = K1 ? 1 : k;
+#pragma unroll 1
+  for (int j = 0; j < n_neighbours; ++j) {
     const long long bj = (long long)b * k + j;
-    const Pose p = p_next;
-    if (j + 1 < k) p_next = load_pose(rel + 16 * (bj + 1));   // in flight behind this neighbour's work
+    // (the pose of a later neighbour is loaded here, at its turn: held in registers across the rows of the
+    // neighbour before it, its 24 scalar registers cost more in spill moves than the 0.3 us it waits now)
+    Pose p = p_next;
+    if (!K1 && j > 0) p = load_pose(rel + 16 * bj);
     const uint16_t* d2 = depth2 + bj * HW;
     const uint8_t* c2 = rgb2 + 3 * bj * HW;
 
@@ -776,17 +781,22 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
-  // tile shape: 128 x 32 pixels on four waves (tuning builds with -DSLAMHIP_TUNING_TILES also hold 128 x 16
-  // on two or four waves, 128 x 24 and 128 x 32 on two waves, chosen by SLAMHIP_TILE; all measured slower)
+  // tile shape (four waves each): 128 x 24 pixels for a single neighbour per anchor - that kernel needs 95
+  // vector registers and 39 KB of LDS, so four workgroups share a compute unit - and 128 x 32 for several
+  // neighbours (168 registers, three workgroups).  Measured per 64-pair launch at k = 1: 78.7 us against 85.2 us
+  // with 128 x 32 and 80.0 us with 128 x 16; at k = 2 and k = 4 the 128 x 32 tile is 3-4 % ahead.
+  // (tuning builds with -DSLAMHIP_TUNING_TILES hold 128 x 16 on two or four waves, 128 x 24 and 128 x 32 on two
+  // or four waves for both kernels, chosen by SLAMHIP_TILE)
 #ifdef SLAMHIP_TUNING_TILES
-  static const int tile_cfg = []() {
+  static const int tile_env = []() {
     const char* e = getenv("SLAMHIP_TILE");
     const std::string v = e ? e : "";
-    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : 0;
+    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : v == "32x16" ? 5 : 0;
   }();
 #else
-  constexpr int tile_cfg = 0;
+  constexpr int tile_env = 0;
 #endif
+  const int tile_cfg = tile_env ? tile_env : (k == 1 ? 3 : 5);
   const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
   FusedArgs a;
   PairAcc* ws = (PairAcc*)workspace;
@@ -824,9 +834,13 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
 #define SLAMHIP_LAUNCH_FUSED(TH_, RPW_)                                                                              \
   do {                                                                                                             \
     const dim3 block(128 * (TH_ / RPW_));                                                                          \
-    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true>), grid, block, 0, s, a, depth1, rgb1,    \
-                                 depth2, rgb2, rel4x4, ws, sums, counts);                                          \
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false>), grid, block, 0, s, a, depth1, rgb1,        \
+    if (unit && k == 1) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true, true>), grid, block, 0, s, a,  \
+                                           depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                  \
+    else if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true, false>), grid, block, 0, s, a,      \
+                                      depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                       \
+    else if (k == 1) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false, true>), grid, block, 0, s, a,    \
+                                        depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                     \
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false, false>), grid, block, 0, s, a, depth1, rgb1, \
                             depth2, rgb2, rel4x4, ws, sums, counts);                                               \
   } while (0)
 #ifdef SLAMHIP_TUNING_TILES
@@ -838,7 +852,8 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
     default: SLAMHIP_LAUNCH_FUSED(32, 16); break;
   }
 #else
-  SLAMHIP_LAUNCH_FUSED(32, 16);
+  if (tile_cfg == 3) SLAMHIP_LAUNCH_FUSED(24, 12);
+  else SLAMHIP_LAUNCH_FUSED(32, 16);
 #endif
 #undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
