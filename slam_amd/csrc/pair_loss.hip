@@ -625,6 +625,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
         return o;
       };
+      // (byte selectors of the anchor colour in scalar registers: as literals they are moved into a vector
+      // register again in every row)
+      unsigned int sel_rg = 0x0c010c00u, sel_b = 0x0c0c0c02u;
+      asm volatile("" : "+s"(sel_rg), "+s"(sel_b));
       Row cur = project_row(0);
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
@@ -632,8 +636,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         if (r + 1 < RPW) nxt = project_row(r + 1);
         if (__builtin_amdgcn_inverse_ballot_w64(cur.m_fast)) {
           const unsigned int argb = a_rgb[r];
-          const unsigned int a_rg = __builtin_amdgcn_perm(0u, argb, 0x0c010c00u);
-          const unsigned int a_b = __builtin_amdgcn_perm(0u, argb, 0x0c0c0c02u);
+          const unsigned int a_rg = __builtin_amdgcn_perm(0u, argb, sel_rg);
+          const unsigned int a_b = __builtin_amdgcn_perm(0u, argb, sel_b);
           blend_accumulate<UNIT>(acc, c_geo, cur.t, cur.fu, cur.fv, inv_factor_f, a_rg, a_b, cur.Z);
         }
         cur = nxt;
