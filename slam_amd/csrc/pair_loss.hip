@@ -263,6 +263,13 @@ struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned
 // waves per SIMD the register allocation must allow: what the LDS windows of TH-row tiles leave room for
 constexpr int fused_waves(int th, int nw) { const int wg = 163840 / (TILE_W + 32) / 8 / win_rows(th); return (wg * nw + 3) / 4 > 8 ? 8 : (wg * nw + 3) / 4; }
 
+// Constants of phase 1 that depend on the pair alone (wave-uniform): see the phase's comments for their meaning.
+struct PairConsts {
+  double kAc, kAr, kA0, kBc, kBr, kB0, kCc, kCr, kC0, t0p, t1p, t2, dz;
+  float half_eps;
+  int cert;
+};
+
 template <int TH, int RPW, bool UNIT, bool K1>
 __global__ void __launch_bounds__(128 * (TH / RPW), fused_waves(TH, 2 * (TH / RPW)))
 pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, const uint8_t* __restrict__ rgb1,
@@ -279,6 +286,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   __shared__ int s_winrec[4];
   __shared__ float s_sum[NW][4];
   __shared__ unsigned int s_cnt[NW][4];
+  __shared__ PairConsts s_pc;
 
   const int H = a.H, W = a.W, k = a.k;
   const Cam cam = a.cam;
@@ -373,6 +381,40 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   unsigned int zmn = 0xffffu, zmx = 0u;
   bool have_range = false;
 
+  // ---- certificate of phase 1 (all values wave-uniform) ----
+  // With S = 65535/factor * (axm |r0j| + aym |r1j| + |r2j|) + |tj| (the largest sum of magnitudes in
+  // the transform of coordinate j), the reference's x', y', z' and the ones of phase 1 each differ from
+  // the real-number value by at most 8 resp. 24 roundings of 2^-53 S (constants, the per-row steps,
+  // the fmas).  For z' above delta_z = 2^-16 Sz the projected coordinate therefore moves by at most
+  //   32 * 2^-53 * 2^17 * (fx Sx / Sz + |u - cx|)  =  2^-31 * (...)  <  eps = 2^-30 * ((fx Sx + fy Sy) / Sz + extent)
+  // (the reciprocal's 2^-48 and the final roundings are covered by the slack of 2), and eps_f, the
+  // threshold applied to the float32 fractions, is twice that (which also covers pixels up to twice
+  // `extent` away from the principal point) and at least 2^-20.
+  // The single-neighbour kernel computes them once per workgroup (wave 1, while wave 0 predicts the window) and
+  // hands them over in LDS: they are some 150 vector instructions that every wave would otherwise repeat.
+  auto pair_consts = [&](const Pose& q) -> PairConsts {
+    PairConsts c;
+    const float zmaxf = 65535.0f * (float)a.inv_fac;
+    const float Sx = zmaxf * (a.axm * fabsf((float)q.r00) + a.aym * fabsf((float)q.r10) + fabsf((float)q.r20)) + fabsf((float)q.t0);
+    const float Sy = zmaxf * (a.axm * fabsf((float)q.r01) + a.aym * fabsf((float)q.r11) + fabsf((float)q.r21)) + fabsf((float)q.t1);
+    const float Sz = zmaxf * (a.axm * fabsf((float)q.r02) + a.aym * fabsf((float)q.r12) + fabsf((float)q.r22)) + fabsf((float)q.t2);
+    const float delta_z = Sz * 0x1p-16f;
+    const float ratio = ((float)cam.fx * Sx + (float)cam.fy * Sy) / Sz;
+    const float eps = 0x1p-30f * (ratio + a.extent);
+    const float eps_f = fmaxf(2.0f * eps, 0x1p-20f);
+    c.cert = (a.cert_ok != 0) && (eps_f <= 0x1p-7f) && (delta_z > 0.0f) && (delta_z < 3.0e38f);   // NaN fails
+    c.half_eps = 0.5f - eps_f;
+    c.dz = (double)delta_z;
+    // u - wx0 + 1 = (z A + t0') / (z C + t2) + (cx - wx0 + 1) with
+    //   A = (col-cx) r00 + (row-cy) (fx/fy) r10 + fx r20,  C = ((col-cx)/fx) r02 + ((row-cy)/fy) r12 + r22
+    // (all divided by factor: z is the raw depth), likewise v; A, B, C advance by a constant per row
+    c.kAc = q.r00 * a.inv_fac; c.kAr = (a.fx_fy * q.r10) * a.inv_fac; c.kA0 = (cam.fx * q.r20) * a.inv_fac;
+    c.kBc = (a.fy_fx * q.r01) * a.inv_fac; c.kBr = q.r11 * a.inv_fac; c.kB0 = (cam.fy * q.r21) * a.inv_fac;
+    c.kCc = q.r02 * a.inv_fx_fac; c.kCr = q.r12 * a.inv_fy_fac; c.kC0 = q.r22 * a.inv_fac;
+    c.t0p = cam.fx * q.t0; c.t1p = cam.fy * q.t1; c.t2 = q.t2;
+    return c;
+  };
+
   // (K1: the kernel for a single neighbour per anchor, which holds no pose of a next neighbour in registers)
   const int n_neighbours = K1 ? 1 : k;
 #pragma unroll 1
@@ -443,6 +485,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
       }
       if (lane == 0) { s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows; }
+    }
+    if constexpr (K1) {
+      if (wave == 1) {
+        const PairConsts c = pair_consts(p);
+        if (lane == 0) s_pc = c;
+      }
     }
     SLAMHIP_STAMP(2);   // window predicted
     __syncthreads();   // also: the previous neighbour's gathers and s_sum / s_cnt reads are done
@@ -516,29 +564,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     unsigned int c_geo = 0u;       // per lane: pixels with four non-zero depth taps (summed over the wave at the end)
     unsigned int rest_bits = 0u;   // bit r: row r of this lane is left to phase 2
 
-    // ---- certificate of phase 1 (all values wave-uniform) ----
-    // With S = 65535/factor * (axm |r0j| + aym |r1j| + |r2j|) + |tj| (the largest sum of magnitudes in
-    // the transform of coordinate j), the reference's x', y', z' and the ones of phase 1 each differ from
-    // the real-number value by at most 8 resp. 24 roundings of 2^-53 S (constants, the per-row steps,
-    // the fmas).  For z' above delta_z = 2^-16 Sz the projected coordinate therefore moves by at most
-    //   32 * 2^-53 * 2^17 * (fx Sx / Sz + |u - cx|)  =  2^-31 * (...)  <  eps = 2^-30 * ((fx Sx + fy Sy) / Sz + extent)
-    // (the reciprocal's 2^-48 and the final roundings are covered by the slack of 2), and eps_f, the
-    // threshold applied to the float32 fractions, is twice that (which also covers pixels up to twice
-    // `extent` away from the principal point) and at least 2^-20.
-    bool cert = a.cert_ok != 0;
-    float eps_f = 0.f, delta_z = 0.f;
-    {
-      const float zmaxf = 65535.0f * (float)a.inv_fac;
-      const float Sx = zmaxf * (a.axm * fabsf((float)p.r00) + a.aym * fabsf((float)p.r10) + fabsf((float)p.r20)) + fabsf((float)p.t0);
-      const float Sy = zmaxf * (a.axm * fabsf((float)p.r01) + a.aym * fabsf((float)p.r11) + fabsf((float)p.r21)) + fabsf((float)p.t1);
-      const float Sz = zmaxf * (a.axm * fabsf((float)p.r02) + a.aym * fabsf((float)p.r12) + fabsf((float)p.r22)) + fabsf((float)p.t2);
-      delta_z = Sz * 0x1p-16f;
-      const float ratio = ((float)cam.fx * Sx + (float)cam.fy * Sy) / Sz;
-      const float eps = 0x1p-30f * (ratio + a.extent);
-      eps_f = fmaxf(2.0f * eps, 0x1p-20f);
-      cert = cert && (eps_f <= 0x1p-7f) && (delta_z > 0.0f) && (delta_z < 3.0e38f);   // NaN fails
-    }
-    const bool cert_u = __builtin_amdgcn_readfirstlane((int)cert) != 0;   // the same in every lane
+    PairConsts pc;
+    if constexpr (K1) pc = s_pc;     // written by wave 1 ahead of the first barrier
+    else pc = pair_consts(p);
+    const bool cert_u = __builtin_amdgcn_readfirstlane(pc.cert) != 0;   // the same in every lane
 
     // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
     // that depends on them alone is computed for all rows ahead of the neighbour loop and held in registers;
@@ -556,19 +585,15 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 #else
     if (cert_u && nrows > 0) {
 #endif
-      // ---- phase 1: u - wx0 + 1 = (z A + t0') / (z C + t2) + (cx - wx0 + 1) with
-      //   A = (col-cx) r00 + (row-cy) (fx/fy) r10 + fx r20,  C = ((col-cx)/fx) r02 + ((row-cy)/fy) r12 + r22
-      // (all divided by factor: z is the raw depth), likewise v; A, B, C advance by a constant per row ----
-      const double kAc = p.r00 * a.inv_fac, kAr = (a.fx_fy * p.r10) * a.inv_fac, kA0 = (cam.fx * p.r20) * a.inv_fac;
-      const double kBc = (a.fy_fx * p.r01) * a.inv_fac, kBr = p.r11 * a.inv_fac, kB0 = (cam.fy * p.r21) * a.inv_fac;
-      const double kCc = p.r02 * a.inv_fx_fac, kCr = p.r12 * a.inv_fy_fac, kC0 = p.r22 * a.inv_fac;
-      double A = fma(ucx, kAc, fma(vcy0, kAr, kA0));
-      double Bq = fma(ucx, kBc, fma(vcy0, kBr, kB0));
-      double C = fma(ucx, kCc, fma(vcy0, kCr, kC0));
-      const double t0p = cam.fx * p.t0, t1p = cam.fy * p.t1, t2 = p.t2;
+      // ---- phase 1 (constants: pair_consts above) ----
+      const double kAr = pc.kAr, kBr = pc.kBr, kCr = pc.kCr;
+      double A = fma(ucx, pc.kAc, fma(vcy0, kAr, pc.kA0));
+      double Bq = fma(ucx, pc.kBc, fma(vcy0, kBr, pc.kB0));
+      double C = fma(ucx, pc.kCc, fma(vcy0, kCr, pc.kC0));
+      const double t0p = pc.t0p, t1p = pc.t1p, t2 = pc.t2;
       const double cxw = cam.cx - (double)(wx0 - 1), cyw = cam.cy - (double)(wy0 - 1);
-      const double dz = (double)delta_z;
-      const float half_eps = 0.5f - eps_f;
+      const double dz = pc.dz;
+      const float half_eps = pc.half_eps;
       // Software pipeline: row r + 1 is projected and its four cells are requested from LDS before row r
       // is blended, so that the LDS latency and the projection's dependent float64 chain overlap the
       // blend of the row before (a row's code is several basic blocks: the compiler cannot do this).
