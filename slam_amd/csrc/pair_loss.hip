@@ -72,6 +72,7 @@ struct FusedArgs {   // everything but the pointers (those are __restrict__ kern
   float axm, aym;      // max |col - cx| / fx and max |row - cy| / fy over the image
   float extent;        // W + H + |cx| + |cy| + 8: bound of |u - cx|, |v - cy| for pixels near the image
   int B, k, H, W, tiles_x, tiles_y;
+  unsigned int inv_k;  // floor(2^32 / k) + 1 for k > 1 (y / k = mulhi(y, inv_k) for y < 2^16), 0 for k == 1
   int stage_vec;       // the window can be staged with 16-byte / 8-byte loads
   int anchor_vec;      // the anchor colour can be read with one 8-byte load per pixel
   int cert_ok;         // the constants are mid-range: phase 1 may certify pixels
@@ -251,7 +252,7 @@ __device__ __forceinline__ void project_f32(const Cam& c, const Pose& p, float u
 // wave 0, written to a buffer of their own that nothing else reads.
 #ifdef SLAMHIP_STAMPS
 static unsigned long long* g_stamps = nullptr;
-#define SLAMHIP_STAMP(i) do { if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SLAMHIP_STAMP(i) do { if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)wg_linear * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SLAMHIP_STAMP(i) do { } while (0)
 #endif
@@ -290,21 +291,29 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
   const int H = a.H, W = a.W, k = a.k;
   const Cam cam = a.cam;
-  // blocks that share (blockIdx % 8) run on one XCD and share its L2: give each
-  // such group whole images so that a tile's halo rows/columns hit in L2.
-  const int tiles = a.tiles_x * a.tiles_y;
+  // Grid: x = 8 * tiles_x (the low three bits are the XCD: workgroups are dealt to the XCDs round-robin by their
+  // linear index, and the x extent is a multiple of 8), y = tiles_y * k (K1) or tiles_y, z = groups of eight anchors.
+  // Whole images go to one XCD, so a tile's halo rows / columns hit in its L2; with K1 a workgroup takes one tile
+  // of ONE (anchor, neighbour) pair, and the k pairs of an anchor tile are 8 * tiles_x workgroups apart on the same
+  // XCD: all but the first find the anchor tile in L2.  Otherwise one tile of an anchor for all its neighbours in
+  // turn.  Everything here is scalar arithmetic (the division by k is a multiplication by its host-made reciprocal).
   const int group = blockIdx.x & 7;
-  const int slot = blockIdx.x >> 3;
-  const int b = (slot / tiles) * 8 + group;
+  const int tx = blockIdx.x >> 3;
+  const unsigned int y = blockIdx.y;
+  const int ty = (K1 && a.inv_k) ? (int)__umulhi(y, a.inv_k) : (int)y;
+  const int j0 = K1 ? (int)y - ty * k : 0;
+  const int b = (int)blockIdx.z * 8 + group;
   if (b >= a.B) return;
-  const int tile = slot % tiles;
-  const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+#ifdef SLAMHIP_STAMPS
+  const size_t wg_linear = blockIdx.x + (size_t)gridDim.x * (blockIdx.y + (size_t)gridDim.y * blockIdx.z);
+#endif
+  const int tiles = a.tiles_x * a.tiles_y;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // known to be wave-uniform
   SLAMHIP_STAMP(0);   // start
 #ifdef SLAMHIP_STAMPS
-  if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + 13] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && wave == 0 && lane == 0) a.stamps[(size_t)wg_linear * 16 + 13] = __builtin_amdgcn_s_memrealtime();
 #endif
   const long long HW = (long long)H * W;
   const int col = tx * TILE_W + (wave & 1) * 64 + lane;
@@ -324,7 +333,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
 
   // the first neighbour's pose is asked for before anything else: the window prediction waits for it
-  Pose p_next = load_pose(rel + 16 * ((long long)b * k));
+  Pose p_next = load_pose(rel + 16 * ((long long)b * k + j0));
 #ifdef SLAMHIP_EXP_POSEWAIT   // diagnostic: how long the pose takes by itself
   asm volatile("s_waitcnt lgkmcnt(0)" :: "s"(p_next.t0), "s"(p_next.r00));
   SLAMHIP_STAMP(15);
@@ -415,10 +424,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     return c;
   };
 
-  // (K1: the kernel for a single neighbour per anchor, which holds no pose of a next neighbour in registers)
-  const int n_neighbours = K1 ? 1 : k;
+  // (K1: straight-line code for the one neighbour j0; the other form walks the anchor's k neighbours)
+  const int j_end = K1 ? j0 + 1 : k;
 #pragma unroll 1
-  for (int j = 0; j < n_neighbours; ++j) {
+  for (int j = j0; j < j_end; ++j) {
     const long long bj = (long long)b * k + j;
     // (the pose of a later neighbour is loaded here, at its turn: held in registers across the rows of the
     // neighbour before it, its 24 scalar registers cost more in spill moves than the 0.3 us it waits now)
@@ -768,7 +777,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       }
       SLAMHIP_STAMP(11);  // ticket drawn
 #ifdef SLAMHIP_STAMPS
-      if (a.stamps && lane == 0) a.stamps[(size_t)blockIdx.x * 16 + 14] = __builtin_amdgcn_s_memrealtime();
+      if (a.stamps && lane == 0) a.stamps[(size_t)wg_linear * 16 + 14] = __builtin_amdgcn_s_memrealtime();
 #endif
     }
     // the next neighbour's first barrier (after the window prediction) orders these reads of s_sum /
@@ -810,22 +819,30 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
-  // tile shape (four waves each): 128 x 24 pixels for a single neighbour per anchor - that kernel needs 95
-  // vector registers and 39 KB of LDS, so four workgroups share a compute unit - and 128 x 32 for several
-  // neighbours (168 registers, three workgroups).  Measured per 64-pair launch at k = 1: 78.7 us against 85.2 us
-  // with 128 x 32 and 80.0 us with 128 x 16; at k = 2 and k = 4 the 128 x 32 tile is 3-4 % ahead.
-  // (tuning builds with -DSLAMHIP_TUNING_TILES hold 128 x 16 on two or four waves, 128 x 24 and 128 x 32 on two
-  // or four waves for both kernels, chosen by SLAMHIP_TILE)
+  // One workgroup per tile of one (anchor, neighbour) pair, 128 x 24 pixels on four waves: that kernel is
+  // straight-line code (no loop over neighbours), needs 89 vector registers and 39 KB of LDS, and four
+  // workgroups share a compute unit.  The form that walks an anchor's k neighbours in one workgroup and reads the
+  // anchor tile once (168 registers, 128 x 32 tiles, three workgroups per compute unit) is slower although it
+  // reads less - the kernel is bound by vector instructions, and the k pairs of an anchor tile run back to
+  // back on one XCD, so the repeated anchor reads come from its L2.  Measured per launch of 64 pairs:
+  // k = 1: 76.5 us against 85.2 us; k = 4 (16 anchors): 71.6 us against 91.7 us.  Tuning builds (-DSLAMHIP_TUNING_TILES) hold the other
+  // tile shapes (SLAMHIP_TILE = 16x16, 16x8, 24x12, 32x16, 32x32) and the shared-anchor form
+  // (SLAMHIP_SHARED_ANCHORS=1).
 #ifdef SLAMHIP_TUNING_TILES
   static const int tile_env = []() {
     const char* e = getenv("SLAMHIP_TILE");
     const std::string v = e ? e : "";
     return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : v == "32x16" ? 5 : 0;
   }();
+  static const bool shared_env = []() { const char* e = getenv("SLAMHIP_SHARED_ANCHORS"); return e && atoi(e) != 0; }();
+  const bool shared_anchors = shared_env && k > 1;
 #else
   constexpr int tile_env = 0;
+  constexpr bool shared_anchors = false;
 #endif
-  const int tile_cfg = tile_env ? tile_env : (k == 1 ? 3 : 5);
+  // (128 x 16 tiles, five workgroups per compute unit, are 3-4 % ahead of 128 x 24 when neighbours share anchors
+  // through L2, and 3 % behind for k = 1)
+  const int tile_cfg = tile_env ? tile_env : (shared_anchors ? 5 : k == 1 ? 3 : 2);
   const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
   FusedArgs a;
   PairAcc* ws = (PairAcc*)workspace;
@@ -834,8 +851,10 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   a.tiles_x = (W + TILE_W - 1) / TILE_W;
   a.tiles_y = (H + tile_h - 1) / tile_h;
   const long long groups = ((long long)B + 7) / 8;
-  const long long nblocks = groups * 8 * a.tiles_x * a.tiles_y;
-  SLAMHIP_REQUIRE(nblocks <= 0x7fffffffLL, SLAMHIP_E_SIZE, "%s: grid too large", who);
+  const long long grid_y = (long long)a.tiles_y * (shared_anchors ? 1 : k);
+  SLAMHIP_REQUIRE(groups <= 65535 && grid_y <= 65535 && 8LL * a.tiles_x <= 0x7fffffffLL, SLAMHIP_E_SIZE,
+                  "%s: grid too large (at most 524280 anchors and 65535 (tile row, neighbour) pairs per call)", who);
+  a.inv_k = k > 1 ? (unsigned int)(0x100000000ULL / (unsigned long long)k) + 1u : 0u;
   // the window staging uses 16-byte / 8-byte vector loads: needs W % 8 == 0 and aligned planes
   a.stage_vec = (W % CHUNK == 0) && aligned_to(depth2, 16) && aligned_to(rgb2, 8);
   a.anchor_vec = (W % 4 == 0) && aligned_to(rgb1, 4);
@@ -859,30 +878,33 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
   const bool unit = factor == 1.0;
-  const dim3 grid((unsigned)nblocks);
-#define SLAMHIP_LAUNCH_FUSED(TH_, RPW_)                                                                              \
+  const dim3 grid(8u * (unsigned)a.tiles_x, (unsigned)grid_y, (unsigned)groups);
+#define SLAMHIP_LAUNCH_FUSED(TH_, RPW_, K1_)                                                                         \
   do {                                                                                                             \
     const dim3 block(128 * (TH_ / RPW_));                                                                          \
-    if (unit && k == 1) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true, true>), grid, block, 0, s, a,  \
-                                           depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                  \
-    else if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true, false>), grid, block, 0, s, a,      \
-                                      depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                       \
-    else if (k == 1) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false, true>), grid, block, 0, s, a,    \
-                                        depth1, rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                     \
-    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false, false>), grid, block, 0, s, a, depth1, rgb1, \
+    if (unit) hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, true, K1_>), grid, block, 0, s, a, depth1,     \
+                                 rgb1, depth2, rgb2, rel4x4, ws, sums, counts);                                    \
+    else hipLaunchKernelGGL((pair_loss_fused_kernel<TH_, RPW_, false, K1_>), grid, block, 0, s, a, depth1, rgb1,   \
                             depth2, rgb2, rel4x4, ws, sums, counts);                                               \
   } while (0)
 #ifdef SLAMHIP_TUNING_TILES
-  switch (tile_cfg) {
-    case 1: SLAMHIP_LAUNCH_FUSED(16, 16); break;
-    case 2: SLAMHIP_LAUNCH_FUSED(16, 8); break;
-    case 3: SLAMHIP_LAUNCH_FUSED(24, 12); break;
-    case 4: SLAMHIP_LAUNCH_FUSED(32, 32); break;
-    default: SLAMHIP_LAUNCH_FUSED(32, 16); break;
+  if (shared_anchors) {
+    switch (tile_cfg) {
+      case 3: SLAMHIP_LAUNCH_FUSED(24, 12, false); break;
+      default: SLAMHIP_LAUNCH_FUSED(32, 16, false); break;
+    }
+  } else {
+    switch (tile_cfg) {
+      case 1: SLAMHIP_LAUNCH_FUSED(16, 16, true); break;
+      case 2: SLAMHIP_LAUNCH_FUSED(16, 8, true); break;
+      case 4: SLAMHIP_LAUNCH_FUSED(32, 32, true); break;
+      case 5: SLAMHIP_LAUNCH_FUSED(32, 16, true); break;
+      default: SLAMHIP_LAUNCH_FUSED(24, 12, true); break;
+    }
   }
 #else
-  if (tile_cfg == 3) SLAMHIP_LAUNCH_FUSED(24, 12);
-  else SLAMHIP_LAUNCH_FUSED(32, 16);
+  if (tile_cfg == 3) SLAMHIP_LAUNCH_FUSED(24, 12, true);
+  else SLAMHIP_LAUNCH_FUSED(16, 8, true);
 #endif
 #undef SLAMHIP_LAUNCH_FUSED
   SLAMHIP_HIP(hipGetLastError());
