@@ -190,6 +190,16 @@ def test_warp_and_fused_small(fp, H, W, factor, dk, ck):
     _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
 
 
+@pytest.mark.parametrize("B,k", [(1, 3), (9, 5), (11, 7), (2, 16)])
+def test_fused_neighbour_counts_and_ragged_batches(fp, B, k):
+    """Neighbour counts that are no powers of two and batches that are no multiples of eight (the grid deals
+    groups of eight anchors to the XCDs and finds the neighbour of a workgroup by a reciprocal multiplication)."""
+    H, W = 50, 136      # two tile columns, three tile rows of 24, ragged on both sides
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    d1, c1, d2, c2, rel = _pairs(B, k, H, W, seed=B * 100 + k, depth_kind="plane", rgb_kind="noise")
+    _check_fused(fp, d1, c1, d2, c2, rel, K, 1.0)
+
+
 @pytest.mark.parametrize("factor,dk,ck,deg", [
     (1.0, "plane", "smooth", 3.0),
     (1.0, "noise", "noise", 3.0),
