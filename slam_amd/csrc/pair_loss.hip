@@ -547,6 +547,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       uint2 cq[NQ][3];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
+        if (q > 0 && q * TPB + wave * 64 >= nchunks) continue;   // (wave-uniform) none of this wave's chunks of this round exists
         const int c = tid + q * TPB;
         const int o = chunk_src(c < nchunks ? c : 0, dst[q]);
         dvq[q] = *reinterpret_cast<const uint4*>(d2 + o);
