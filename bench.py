@@ -324,8 +324,8 @@ def main():
                           os.path.join(ROOT, "slam_amd", "csrc", "pair_loss.hip"))
         if tr is not None and (B, k, H, W) == (64, 1, 480, 640) and a.factor == 1.0 and a.depth == "plane":
             traffic = tr["hbm_bytes_per_launch"]
-            traffic_src = "profiles/r2_traffic_fused.json (rocprofv3 --pmc FETCH_SIZE x %.2f + WRITE_SIZE; kernel source %s)" % (
-                tr.get("fetch_size_factor", 2.0), tr["source_sha256"][:12])
+            traffic_src = ("profiles/r2_traffic_fused.json (rocprofv3 --pmc: L2 read requests by size, 32 n32 + 64 n64 + 128 n128 "
+                           "= FETCH_SIZE x %.2f, + WRITE_SIZE; kernel source %s)" % (tr.get("fetch_size_factor", 2.0), tr["source_sha256"][:12]))
         pairs = world * B * k * a.steps
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         line = {
