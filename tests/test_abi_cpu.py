@@ -71,6 +71,13 @@ def test_version_and_error_text():
     rc = lib.slamhip_adam_step_shadow(None, p8, p8, p8, 10, 0.01, 0.9, 0.999, 1e-8, 1, 1.0, None, 0, None)
     assert rc == -1
     assert lib.slamhip_transpose_bf16(None, p8, 8, 8, None) == -1
+    # the launch grid's extents bound a call: (tile rows x neighbours) and groups of eight anchors at most 65535
+    a16 = ctypes.c_void_p(4096)
+    for B, k, H in ((1, 70000, 24), (8 * 65535 + 1, 1, 24), (1, 100, 24 * 700)):
+        need = lib.slamhip_pair_loss_workspace_bytes(B, k)
+        rc = lib.slamhip_pair_loss_fused(a16, a16, a16, a16, a16, capi.K4([500, 500, 64, 12]), 1.0, B, k, H, 128,
+                                         a16, a16, a16, need, None)
+        assert rc == -3 and b"grid too large" in lib.slamhip_last_error(), (B, k, H, rc, lib.slamhip_last_error())
     assert lib.slamhip_pair_loss_workspace_bytes(64, 1) == 64 * 64
     assert lib.slamhip_pair_loss_workspace_bytes(3, 4) == 3 * 4 * 64
 
