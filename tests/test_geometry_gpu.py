@@ -200,6 +200,23 @@ def test_fused_neighbour_counts_and_ragged_batches(fp, B, k):
     _check_fused(fp, d1, c1, d2, c2, rel, K, 1.0)
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_fused_random_shapes(fp, seed):
+    """Seeded random draws of every launch parameter at once: batch, neighbour count, frame size (partial
+    tiles on either side), depth factor, scene kind, rotation and translation range."""
+    rs = np.random.RandomState(9000 + seed)
+    B, k = int(rs.randint(1, 12)), int(rs.randint(1, 7))
+    H, W = int(rs.randint(3, 80)), int(rs.randint(3, 300))
+    factor = float(rs.choice([1.0, 1000.0, 5000.0]))
+    dk, ck = str(rs.choice(["plane", "noise"])), str(rs.choice(["smooth", "noise"]))
+    deg, t = float(rs.choice([0.5, 3.0, 25.0])), float(rs.choice([0.0, 0.05, 0.5]))
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    d1, c1, d2, c2, rel = _pairs(B, k, H, W, seed=seed + 77, depth_kind=dk, rgb_kind=ck, max_deg=deg, max_t=t)
+    _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+    if B * k <= 12:
+        _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+
+
 @pytest.mark.parametrize("factor,dk,ck,deg", [
     (1.0, "plane", "smooth", 3.0),
     (1.0, "noise", "noise", 3.0),
