@@ -267,7 +267,14 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
                         float* __restrict__ stat_part, int m_tile0) {
   constexpr int BM = 256, BN = 64, AR = BM + 2;
   constexpr int NBV = 3 * BN / 32;            // 16-byte B loads per thread and step
-  __shared__ __attribute__((aligned(16))) bf16 As[AR * LDS_PITCH];
+#ifdef SLAMHIP_ABL_R3
+  // timing-only ablations (wrong results): bit 0 no LDS stores, 1 no global loads after the first two steps,
+  // 2 no output stores, 3 no fragment masks
+  constexpr int ABL = SLAMHIP_ABL_R3;
+#else
+  constexpr int ABL = 0;
+#endif
+  __shared__ __attribute__((aligned(16))) bf16 As[(AR + 1) * LDS_PITCH];   // staged row AR holds zeros
   __shared__ __attribute__((aligned(16))) bf16 Bs[3 * BN * LDS_PITCH];
 
   const int per_xcd = (total_tiles + 7) >> 3;
@@ -276,6 +283,9 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
   const int m0 = (m_tile0 + work / n_tiles) * BM, n0 = (work % n_tiles) * BN;   // m_tile0: first pixel tile of this launch
 
   const int tid = threadIdx.x, lane = tid & 63, wm = tid >> 6;
+  // a tap outside the image reads the row of zeros instead of its pixel: one address select per fragment
+  // row and tap in place of a mask on every fragment
+  if (tid < LDS_PITCH / 8) *reinterpret_cast<uint4*>(&As[AR * LDS_PITCH + tid * 8]) = make_uint4(0u, 0u, 0u, 0u);
   const int Ktot = 9 * C;
 
   // A loader: eight passes; in pass v thread -> staged row (tid >> 3) + 32 v (pixel m0 - 1 + row),
@@ -284,14 +294,11 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
   const int a_row = tid >> 3, a_chunk = tid & 7;
   const int h_row = BM + (tid >> 3), h_chunk = tid & 7;
   const bool has_halo = tid < 16;
-  const bf16* b_src[NBV];
-  int b_dst[NBV];
-#pragma unroll
-  for (int v = 0; v < NBV; ++v) {
-    const int id = tid + 256 * v, e = id / (BN * 8), rem = id - e * (BN * 8), n = rem >> 3, ch = rem & 7;
-    b_src[v] = Bw + (long long)(n0 + n) * Ktot + e * C + ch * 8;
-    b_dst[v] = (e * BN + n) * LDS_PITCH + ch * 8;
-  }
+  // B loader: load v of a step brings weight slot e = v >> 1, output channel (tid >> 3) + 32 (v & 1), 16-byte
+  // chunk tid & 7: one pointer and one LDS offset per thread, the rest are uniform offsets
+  const bf16* const b_src0 = Bw + (long long)(n0 + (tid >> 3)) * Ktot + (tid & 7) * 8;
+  const int b_dst0 = (tid >> 3) * LDS_PITCH + (tid & 7) * 8;
+  const long long b_half = 32LL * Ktot;
 
   // validity of the nine taps of this lane's two fragment rows (pixels)
   unsigned int fm[2];
@@ -339,43 +346,50 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
       rah[set] = *reinterpret_cast<const uint4*>(A + qh * C + c0 + h_chunk * 8);                 \
     }                                                                                            \
     _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
-      rb[set][v] = *reinterpret_cast<const uint4*>(b_src[v] + g * 3 * C + c0);                   \
+      rb[set][v] = *reinterpret_cast<const uint4*>(b_src0 + (v & 1) * b_half + ((v >> 1) + g * 3) * C + c0); \
     c0 += 64;                                                                                    \
     if (c0 == C) { c0 = 0; ++g; }                                                                \
+  }
+
+  // fragments of sub-step it_ of the staged K-step into fragment set buf_ (staged row = pixel row + 1 + dx)
+  bf16x8 fa[2][2], fb[2][2];
+#define SLAMHIP_ROW3W_FRAGS(buf_, it_)                                                           \
+  {                                                                                              \
+    const int e_ = (it_) >> 2, kk_ = ((it_) & 3) * 16;                                           \
+    const int shift_ = flip ? 2 - e_ : e_;                                                       \
+    const int t_ = flip ? 8 - (g_cur * 3 + e_) : g_cur * 3 + e_;   /* geometric tap of weight slot (g_cur, e_) */ \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                              \
+      const int row_ = (((fm[i] >> t_) & 1u) || (ABL & 8)) ? wm * 64 + i * 32 + (lane & 31) + shift_ : AR; \
+      fa[buf_][i] = *reinterpret_cast<const bf16x8*>(&As[row_ * LDS_PITCH + kk_ + 8 * (lane >> 5)]); \
+    }                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                \
+      fb[buf_][j] = *reinterpret_cast<const bf16x8*>(                                            \
+          &Bs[(e_ * BN + j * 32 + (lane & 31)) * LDS_PITCH + kk_ + 8 * (lane >> 5)]);            \
   }
 
   // one K-step from register set `set`; `more`: a step two ahead exists and is requested
 #define SLAMHIP_ROW3W_STEP(set, more)                                                            \
   {                                                                                              \
     __syncthreads();   /* the previous step's fragments have been read */                        \
-    {                                                                                            \
+    if (!(ABL & 1) || s == 0) {                                                                  \
       _Pragma("unroll") for (int v = 0; v < 8; ++v)                                              \
         *reinterpret_cast<uint4*>(&As[(a_row + 32 * v) * LDS_PITCH + a_chunk * 8]) = and4(ra[set][v], b_keep); \
       if (has_halo) *reinterpret_cast<uint4*>(&As[h_row * LDS_PITCH + h_chunk * 8]) = rah[set];  \
+      _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                            \
+        *reinterpret_cast<uint4*>(&Bs[b_dst0 + ((v >> 1) * BN + 32 * (v & 1)) * LDS_PITCH]) = and4(rb[set][v], b_keep); \
     }                                                                                            \
-    _Pragma("unroll") for (int v = 0; v < NBV; ++v)                                              \
-      *reinterpret_cast<uint4*>(&Bs[b_dst[v]]) = and4(rb[set][v], b_keep);                       \
     __syncthreads();                                                                             \
-    if (more) SLAMHIP_ROW3W_ISSUE(set);   /* in flight while the matrix cores work */            \
-    _Pragma("unroll") for (int e = 0; e < 3; ++e) {                                              \
-      const int t = flip ? 8 - (g_cur * 3 + e) : g_cur * 3 + e;   /* geometric tap of weight slot (g_cur, e) */ \
-      const int shift = flip ? 2 - e : e;                         /* staged row = pixel row + 1 + dx */ \
-      uint32_t keep[2];                                                                          \
-      _Pragma("unroll") for (int i = 0; i < 2; ++i) keep[i] = ((fm[i] >> t) & 1u) ? 0xffffffffu : 0u; \
-      _Pragma("unroll") for (int kk = 0; kk < 64; kk += 16) {                                    \
-        bf16x8 af[2], bfr[2];                                                                    \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                          \
-          const uint4 raw = *reinterpret_cast<const uint4*>(                                     \
-              &As[(wm * 64 + i * 32 + (lane & 31) + shift) * LDS_PITCH + kk + 8 * (lane >> 5)]); \
-          af[i] = __builtin_bit_cast(bf16x8, and4(raw, keep[i]));                                \
-        }                                                                                        \
+    if ((more) && !(ABL & 2)) SLAMHIP_ROW3W_ISSUE(set);   /* in flight while the matrix cores work */ \
+    /* twelve sub-steps (weight slot e, 16 channels): the fragments of sub-step it + 1 are read */ \
+    /* while the MFMAs of sub-step it run (two fragment register sets) */                        \
+    SLAMHIP_ROW3W_FRAGS(0, 0);                                                                   \
+    _Pragma("unroll") for (int it = 0; it < 12; ++it) {                                          \
+      if (it + 1 < 12) SLAMHIP_ROW3W_FRAGS((it + 1) & 1, it + 1);                                \
+      __builtin_amdgcn_sched_barrier(0);   /* keep the reads ahead of this sub-step's MFMAs */    \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                              \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
-          bfr[j] = *reinterpret_cast<const bf16x8*>(                                             \
-              &Bs[(e * BN + j * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);          \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                            \
-          _Pragma("unroll") for (int j = 0; j < 2; ++j)                                          \
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0); \
-      }                                                                                          \
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it & 1][i], fb[it & 1][j], acc[i][j], 0, 0, 0); \
+      __builtin_amdgcn_sched_barrier(0);                                                         \
     }                                                                                            \
     c_cur += 64;                                                                                 \
     if (c_cur == C) { c_cur = 0; ++g_cur; }                                                      \
@@ -389,8 +403,20 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
     if (s + 1 < ksteps) SLAMHIP_ROW3W_STEP(1, s + 3 < ksteps);
   }
 #undef SLAMHIP_ROW3W_STEP
+#undef SLAMHIP_ROW3W_FRAGS
 #undef SLAMHIP_ROW3W_ISSUE
 
+  if (ABL & 16) {   // no epilogue: one store that never happens keeps the accumulators alive
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 12345.678f) out_bf16[tid] = (bf16)t;
+    return;
+  }
   // the 256 x 64 output tile leaves through LDS (the A tile's space): rows of 128 bytes, written
   // to memory as 16-byte chunks, eight lanes per row
   __syncthreads();   // the last step's fragments have been read
@@ -406,13 +432,13 @@ igemm_row3w_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw,
 #pragma unroll
   for (int v = 0; v < 8; ++v) {
     const int id = tid + 256 * v, row = id >> 3, c8 = id & 7;
-    if (m0 + row < M)
+    if (m0 + row < M && (!(ABL & 4) || As[row * LDS_PITCH + c8 * 8] == (bf16)12345.f))
       *reinterpret_cast<uint4*>(out_bf16 + (long long)(m0 + row) * N + n0 + c8 * 8) =
           *reinterpret_cast<const uint4*>(&As[row * LDS_PITCH + c8 * 8]);
   }
   // records are counted in 64-row groups, two per 128 pixel rows; a wave wholly beyond the last
   // 128-row tile holds zeros and leaves no record
-  if (stat_part && m0 / 64 + wm < (M + 127) / 128 * 2) {
+  if (!(ABL & 32) && stat_part && m0 / 64 + wm < (M + 127) / 128 * 2) {
     float* part = stat_part + ((long long)(work / n_tiles) * 4 + wm) * 2 * N;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
