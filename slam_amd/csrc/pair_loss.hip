@@ -261,6 +261,36 @@ struct __attribute__((aligned(4))) Dword2 {   // eight bytes at a 4-byte-aligned
   unsigned int x, y;
 };
 
+// The kernel's parameter list as it lies in the kernel-argument segment.  The single-neighbour kernel reads
+// what its rare and late parts need (the exact phase: camera, pose, plane pointers; the publication: workspace and
+// outputs) from there at the point of use, through a pointer the optimiser cannot see through: kept from the
+// kernel's start they are some 50 scalar registers that live across the row loop, and the ones beyond the
+// register file are parked in vector-register lanes, one vector instruction per move.
+struct FusedKernArgs {
+  FusedArgs a;
+  const uint16_t* depth1; const uint8_t* rgb1; const uint16_t* depth2; const uint8_t* rgb2;
+  const double* rel; PairAcc* ws; double* sums; unsigned int* counts;
+};
+static_assert(offsetof(FusedKernArgs, depth1) == sizeof(FusedArgs) && sizeof(FusedArgs) % 8 == 0, "kernel-argument layout");
+typedef const __attribute__((address_space(4))) FusedKernArgs* KernArgPtr;
+typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+
+__device__ __forceinline__ KernArgPtr late_kernargs() {
+  KernArgPtr q = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(q));
+  return q;
+}
+
+// the pose through the constant address space (the matrices are not written while the kernel runs): scalar loads
+__device__ __forceinline__ Pose load_pose_const(const double* m) {
+  const ConstF64Ptr c = (ConstF64Ptr)(unsigned long long)m;
+  Pose p;
+  p.r00 = c[0]; p.r01 = c[1]; p.r02 = c[2]; p.t0 = c[3];
+  p.r10 = c[4]; p.r11 = c[5]; p.r12 = c[6]; p.t1 = c[7];
+  p.r20 = c[8]; p.r21 = c[9]; p.r22 = c[10]; p.t2 = c[11];
+  return p;
+}
+
 // waves per SIMD the register allocation must allow: what the LDS windows of TH-row tiles leave room for
 constexpr int fused_waves(int th, int nw) { const int wg = 163840 / (TILE_W + 32) / 8 / win_rows(th); return (wg * nw + 3) / 4 > 8 ? 8 : (wg * nw + 3) / 4; }
 
@@ -690,6 +720,21 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 #endif
     if (__builtin_amdgcn_ballot_w64(rest_bits != 0u) != 0ull) {
       const double dW = (double)W, dH = (double)H, dW1 = (double)(W - 1), dH1 = (double)(H - 1);
+      // (single-neighbour kernel: camera, pose and plane pointers from the kernel arguments, see FusedKernArgs)
+      Cam cam2 = cam;
+      Pose p2 = p;
+      const uint16_t* d1x = d1b;
+      const uint8_t* c1x = c1b;
+      const uint16_t* d2x = d2;
+      const uint8_t* c2x = c2;
+      if constexpr (K1) {
+        const KernArgPtr q = late_kernargs();
+        cam2.fx = q->a.cam.fx; cam2.fy = q->a.cam.fy; cam2.cx = q->a.cam.cx; cam2.cy = q->a.cam.cy;
+        cam2.factor = q->a.cam.factor;
+        p2 = load_pose_const(q->rel + 16 * bj);
+        d1x = q->depth1 + (long long)b * HW; c1x = q->rgb1 + 3 * (long long)b * HW;
+        d2x = q->depth2 + bj * HW; c2x = q->rgb2 + 3 * bj * HW;
+      }
 #pragma unroll 1
       for (int r = 0; r < RPW; ++r) {
         const bool need = (rest_bits >> r) & 1u;
@@ -698,12 +743,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         if (need) {
           const int row = row0 + r;
           const long long o = (long long)row * W + col;
-          const unsigned int draw = d1b[o];
+          const unsigned int draw = d1x[o];
           double x, y, z, x2, y2, z2, u, v;
-          backproject_px(cam, col, row, draw, x, y, z);
+          backproject_px(cam2, col, row, draw, x, y, z);
           valid0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
-          transform_px(p, x, y, z, x2, y2, z2);
-          project_px(cam, x2, y2, z2, u, v);
+          transform_px(p2, x, y, z, x2, y2, z2);
+          project_px(cam2, x2, y2, z2, u, v);
           inb = valid0 && in_window(u, v, dW, dH);
           wv = valid0 && in_window(u, v, dW1, dH1) && (z2 > 0.0);
           if (wv) {
@@ -717,10 +762,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
               t = read_cells(win, dv * WIN_PITCH + du);
             } else {
               const int x1 = min(iu + 1, W - 1), y1 = min(iv + 1, H - 1);
-              t.a = global_cell(d2, c2, W, iu, iv); t.b = global_cell(d2, c2, W, x1, iv);
-              t.c = global_cell(d2, c2, W, iu, y1); t.e = global_cell(d2, c2, W, x1, y1);
+              t.a = global_cell(d2x, c2x, W, iu, iv); t.b = global_cell(d2x, c2x, W, x1, iv);
+              t.c = global_cell(d2x, c2x, W, iu, y1); t.e = global_cell(d2x, c2x, W, x1, y1);
             }
-            const uint8_t* cp = c1b + 3 * o;
+            const uint8_t* cp = c1x + 3 * o;
             const unsigned int rgbx = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
             const unsigned int a_rg = __builtin_amdgcn_perm(0u, rgbx, 0x0c010c00u);
             const unsigned int a_b = __builtin_amdgcn_perm(0u, rgbx, 0x0c0c0c02u);
@@ -748,6 +793,16 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     SLAMHIP_STAMP(10);  // all waves reduced
     if (wave == 0) {
       PairAcc* pa = ws + bj;
+      double* sums_out = sums;
+      unsigned int* counts_out = counts;
+      unsigned int last_ticket = (unsigned int)tiles - 1u;
+      if constexpr (K1) {
+        const KernArgPtr q = late_kernargs();
+        pa = q->ws + bj;
+        sums_out = q->sums;
+        counts_out = q->counts;
+        last_ticket = (unsigned int)(q->a.tiles_x * q->a.tiles_y) - 1u;
+      }
       if (lane < 4) {
         double t = (double)s_sum[0][lane] + (double)s_sum[1][lane];
         if (NW == 4) t += (double)s_sum[2][lane] + (double)s_sum[3][lane];
@@ -766,14 +821,14 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       unsigned int t = 0;
       if (lane == 0) t = atomicAdd(&pa->ticket, 1u);
       t = __builtin_amdgcn_readfirstlane(t);
-      if (t == (unsigned int)tiles - 1u) {
+      if (t == last_ticket) {
         // last workgroup of this pair: totals out, accumulators back to zero
         // (the lane number is made opaque here: the output addresses are otherwise computed ahead of the
         // neighbour loop and, with every register taken by the rows, kept in scratch memory)
         unsigned int pl = (unsigned int)lane;
         asm volatile("" : "+v"(pl));
-        if (pl < 4) sums[bj * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
-        else if (pl < 8) counts[bj * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
+        if (pl < 4) sums_out[bj * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
+        else if (pl < 8) counts_out[bj * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
         else if (pl == 8) atomicExch(&pa->ticket, 0u);
       }
       SLAMHIP_STAMP(11);  // ticket drawn
