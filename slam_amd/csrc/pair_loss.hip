@@ -353,14 +353,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   const uint8_t* c1b = rgb1 + 3 * (long long)b * HW;
 
   // rows of this wave inside the image, and of those the rows with row - cy != 0
-  unsigned int rows_in = 0u, rows_nz = 0u;
-#pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    rows_in |= (row0 + r < H) ? (1u << r) : 0u;
-    rows_nz |= (row0 + r < H && row0 + r != a.cy_row) ? (1u << r) : 0u;
-  }
-  const unsigned long long col_in = __builtin_amdgcn_ballot_w64(col < W);
-  const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
+  // (closed forms: as a chain of per-row compares the masks are rebuilt where they are used, and the twelve row
+  // numbers and compare results live in scalar registers until then)
+  const int n_in = min(max(H - row0, 0), RPW);
+  unsigned int rows_in = (n_in >= 32) ? 0xffffffffu : ((1u << n_in) - 1u);
+  const unsigned int rz = (unsigned int)(a.cy_row - row0);
+  unsigned int rows_nz = rows_in & ~((rz < (unsigned int)RPW) ? (1u << rz) : 0u);
 
   // the first neighbour's pose is asked for before anything else: the window prediction waits for it
   Pose p_next = load_pose(rel + 16 * ((long long)b * k + j0));
@@ -620,6 +618,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
     }
     asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
+    // columns of this wave inside the image, and of those the ones with col - cx != 0 (made here, at their use:
+    // held from the kernel's start the two masks are parked in vector lanes across the staging)
+    int colq = col;
+    asm volatile("" : "+v"(colq));
+    const unsigned long long col_in = __builtin_amdgcn_ballot_w64(colq < W);
+    const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(colq < W && colq != a.cx_col);
 #ifdef SLAMHIP_ABL_NO_PHASE1     // timing ablation only: results are wrong
     if (false) {
 #else
@@ -729,11 +733,14 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       const uint8_t* c2x = c2;
       if constexpr (K1) {
         const KernArgPtr q = late_kernargs();
+        long long bq = b, bjq = bj;     // (opaque: the plane offsets are multiplied out here, not kept from the start)
+        asm volatile("" : "+s"(bq), "+s"(bjq));
         cam2.fx = q->a.cam.fx; cam2.fy = q->a.cam.fy; cam2.cx = q->a.cam.cx; cam2.cy = q->a.cam.cy;
         cam2.factor = q->a.cam.factor;
-        p2 = load_pose_const(q->rel + 16 * bj);
-        d1x = q->depth1 + (long long)b * HW; c1x = q->rgb1 + 3 * (long long)b * HW;
-        d2x = q->depth2 + bj * HW; c2x = q->rgb2 + 3 * bj * HW;
+        p2 = load_pose_const(q->rel + 16 * bjq);
+        const long long HWq = (long long)q->a.H * q->a.W;
+        d1x = q->depth1 + bq * HWq; c1x = q->rgb1 + 3 * bq * HWq;
+        d2x = q->depth2 + bjq * HWq; c2x = q->rgb2 + 3 * bjq * HWq;
       }
 #pragma unroll 1
       for (int r = 0; r < RPW; ++r) {
@@ -796,19 +803,25 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       double* sums_out = sums;
       unsigned int* counts_out = counts;
       unsigned int last_ticket = (unsigned int)tiles - 1u;
+      long long bjo = bj;
+      // (the lane number is made opaque here: the lane masks and output addresses are otherwise computed ahead of
+      // the rows and, with every register taken there, parked in vector lanes or scratch memory)
+      unsigned int pl = (unsigned int)lane;
+      asm volatile("" : "+v"(pl));
       if constexpr (K1) {
         const KernArgPtr q = late_kernargs();
-        pa = q->ws + bj;
+        asm volatile("" : "+s"(bjo));
+        pa = q->ws + bjo;
         sums_out = q->sums;
         counts_out = q->counts;
         last_ticket = (unsigned int)(q->a.tiles_x * q->a.tiles_y) - 1u;
       }
-      if (lane < 4) {
-        double t = (double)s_sum[0][lane] + (double)s_sum[1][lane];
-        if (NW == 4) t += (double)s_sum[2][lane] + (double)s_sum[3][lane];
-        atomicAdd(&pa->sums[lane], t);
-      } else if (lane < 8) {
-        const int q = lane - 4;
+      if (pl < 4) {
+        double t = (double)s_sum[0][pl] + (double)s_sum[1][pl];
+        if (NW == 4) t += (double)s_sum[2][pl] + (double)s_sum[3][pl];
+        atomicAdd(&pa->sums[pl], t);
+      } else if (pl < 8) {
+        const int q = (int)pl - 4;
         unsigned int c = s_cnt[0][q] + s_cnt[1][q];
         if (NW == 4) c += s_cnt[2][q] + s_cnt[3][q];
         atomicAdd(&pa->counts[q], c);
@@ -819,16 +832,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       // every add of this workgroup has been performed before its ticket is drawn
       __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
       unsigned int t = 0;
-      if (lane == 0) t = atomicAdd(&pa->ticket, 1u);
+      if (pl == 0) t = atomicAdd(&pa->ticket, 1u);
       t = __builtin_amdgcn_readfirstlane(t);
       if (t == last_ticket) {
         // last workgroup of this pair: totals out, accumulators back to zero
-        // (the lane number is made opaque here: the output addresses are otherwise computed ahead of the
-        // neighbour loop and, with every register taken by the rows, kept in scratch memory)
-        unsigned int pl = (unsigned int)lane;
-        asm volatile("" : "+v"(pl));
-        if (pl < 4) sums_out[bj * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
-        else if (pl < 8) counts_out[bj * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
+        if (pl < 4) sums_out[bjo * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
+        else if (pl < 8) counts_out[bjo * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
         else if (pl == 8) atomicExch(&pa->ticket, 0u);
       }
       SLAMHIP_STAMP(11);  // ticket drawn
