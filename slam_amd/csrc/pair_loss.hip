@@ -169,7 +169,8 @@ __device__ __forceinline__ unsigned int wave_pk_max63(unsigned int v) {
 }
 
 struct Acc {   // per-thread partial sums of one neighbour frame
-  float ap, sp, ag, sg;
+  float ap, sp;    // photometric: |r| and r^2 on the cells' scale (2^-24 and 2^-48 of the sums)
+  double ag, sg;   // geometric: the residual is formed in float64 and is summed there (no conversion per pixel)
 };
 
 struct Cells {  // the four taps of one pixel
@@ -189,43 +190,40 @@ __device__ __forceinline__ bool taps_nonzero(const Cells& t) {  // all four raw 
   return min(min(t.a.y, t.b.y), min(t.c.y, t.e.y)) >= 0x10000u;
 }
 
-// Bilinear blend of one pixel and its contribution to the sums.  Interpolation order as
-// in the oracle (top row, bottom row, then vertical) with fused multiply-adds; the
-// deviation from the unfused float32 oracle is a few 1e-7.  Colour differences are exact
-// in binary16; each horizontal lerp is one mixed-precision fma.  a_rg / a_b: the anchor's
-// colour in the cells' form, bytes R | G << 16 and B (binary16 subnormals, the colour times 2^-24);
-// acc.ap and acc.sp therefore collect 2^-24 and 2^-48 of the photometric sums.  z2: the transformed depth (float64).  c_geo counts the pixels that also have
-// four non-zero depth taps.  Runs only on lanes whose pixel warps (warp_valid).
+// Bilinear blend of one pixel and its contribution to the sums, by the four tap weights
+//   w11 = fu fv, w10 = fu - w11, w01 = fv - w11, w00 = (1 - fu) - w01
+// (each exact to an ulp of float32, their sum 1 to 2^-23): warped - anchor is a chain of four mixed-precision
+// fmas per colour channel that starts from the negated anchor, the cells' binary16 colours read in place; the
+// depth taps are converted and blended the same way.  The deviation from the oracle's unfused float32
+// lerps (top row, bottom row, vertical) is a few 1e-7.  a_rg / a_b: the anchor's colour in the cells'
+// form, bytes R | G << 16 and B (binary16 subnormals, the colour times 2^-24); acc.ap and acc.sp therefore
+// collect 2^-24 and 2^-48 of the photometric sums.  z2: the transformed depth (float64).  geo: the pixel also
+// has four non-zero depth taps (taps_nonzero; the caller counts these pixels from the lane mask, outside
+// the divergent region, so that the count stays a scalar).  Runs only on lanes whose pixel warps (warp_valid).
 template <bool UNIT>
-__device__ __forceinline__ void blend_accumulate(Acc& acc, unsigned int& c_geo, const Cells& t, float fu, float fv,
+__device__ __forceinline__ void blend_accumulate(Acc& acc, const bool geo, const Cells& t, float fu, float fv,
                                                  float inv_factor_f, unsigned int a_rg, unsigned int a_b, double z2) {
-  const half2_t aRG = as_half2(t.a.x), cRG = as_half2(t.c.x);
-  const half2_t dT = as_half2(t.b.x) - aRG, dB = as_half2(t.e.x) - cRG;
-  const _Float16 aB = as_half2(t.a.y).x, cB = as_half2(t.c.y).x;
-  const _Float16 dTb = as_half2(t.b.y).x - aB, dBb = as_half2(t.e.y).x - cB;
-  const float tr = __builtin_fmaf(fu, (float)dT.x, (float)aRG.x), br = __builtin_fmaf(fu, (float)dB.x, (float)cRG.x);
-  const float tg = __builtin_fmaf(fu, (float)dT.y, (float)aRG.y), bg = __builtin_fmaf(fu, (float)dB.y, (float)cRG.y);
-  const float tb = __builtin_fmaf(fu, (float)dTb, (float)aB), bb = __builtin_fmaf(fu, (float)dBb, (float)cB);
-  const float wr = __builtin_fmaf(fv, br - tr, tr), wg = __builtin_fmaf(fv, bg - tg, tg);
-  const float wb = __builtin_fmaf(fv, bb - tb, tb);
-  // anchor - warped (the sign is irrelevant to |r| and r^2): one mixed-precision fma per channel,
-  // the anchor (scaled like the cells) read as binary16 in place
-  float rr, rg, rb;
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rr) : "v"(wr), "v"(a_rg));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rg) : "v"(wg), "v"(a_rg));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(wb), "v"(a_b));
+  const float w11 = fu * fv, w10 = fu - w11, w01 = fv - w11, w00 = (1.0f - fu) - w01;
+  const half2_t aRG = as_half2(t.a.x), bRG = as_half2(t.b.x), cRG = as_half2(t.c.x), eRG = as_half2(t.e.x);
+  const _Float16 aB = as_half2(t.a.y).x, bB = as_half2(t.b.y).x, cB = as_half2(t.c.y).x, eB = as_half2(t.e.y).x;
+  const half2_t nRG = as_half2(a_rg);
+  const _Float16 nB = as_half2(a_b).x;
+  // warped - anchor (the sign is irrelevant to |r| and r^2)
+  float rr = __builtin_fmaf(w00, (float)aRG.x, -(float)nRG.x), rg = __builtin_fmaf(w00, (float)aRG.y, -(float)nRG.y);
+  float rb = __builtin_fmaf(w00, (float)aB, -(float)nB);
+  rr = __builtin_fmaf(w10, (float)bRG.x, rr); rg = __builtin_fmaf(w10, (float)bRG.y, rg); rb = __builtin_fmaf(w10, (float)bB, rb);
+  rr = __builtin_fmaf(w01, (float)cRG.x, rr); rg = __builtin_fmaf(w01, (float)cRG.y, rg); rb = __builtin_fmaf(w01, (float)cB, rb);
+  rr = __builtin_fmaf(w11, (float)eRG.x, rr); rg = __builtin_fmaf(w11, (float)eRG.y, rg); rb = __builtin_fmaf(w11, (float)eB, rb);
   acc.ap = ((acc.ap + fabsf(rr)) + fabsf(rg)) + fabsf(rb);
   acc.sp = __builtin_fmaf(rb, rb, __builtin_fmaf(rg, rg, __builtin_fmaf(rr, rr, acc.sp)));
-  if (taps_nonzero(t)) {   // geo_valid: the depth channel and its residual
+  if (geo) {   // geo_valid: the depth channel and its residual
     const float da = (float)(t.a.y >> 16), db = (float)(t.b.y >> 16), dc = (float)(t.c.y >> 16), de = (float)(t.e.y >> 16);
-    const float td = __builtin_fmaf(fu, db - da, da), bd = __builtin_fmaf(fu, de - dc, dc);
-    const float w3 = __builtin_fmaf(fv, bd - td, td);
+    const float w3 = __builtin_fmaf(w11, de, __builtin_fmaf(w01, dc, __builtin_fmaf(w10, db, w00 * da)));
     const float wd = UNIT ? w3 : w3 * inv_factor_f;
     // in float64: test_import's d is float64 and may be far larger than the residual
-    const float g = (float)((double)wd - z2);
-    acc.ag += fabsf(g);
-    acc.sg = __builtin_fmaf(g, g, acc.sg);
-    c_geo += 1u;
+    const double g = (double)wd - z2;
+    acc.ag += fabs(g);
+    acc.sg = fma(g, g, acc.sg);
   }
 }
 
@@ -369,9 +367,11 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
   // ---- anchor pixels of this lane: raw depth and the eight bytes that hold the colour, read once per tile;
   // nothing here waits for the loads: they stay in flight behind the window prediction and the staging ----
-  unsigned int a_d[RPW], a_rgb[RPW];
+  unsigned int a_d[RPW];
   Dword2 a_q[RPW];
-  unsigned int a_sel;   // byte selector that turns a_q into {R, G, B, 0}
+  // byte selectors that turn a_q into the cells' form of the colour: {R, 0, G, 0} and {B, 0, 0, 0} (a byte read as
+  // binary16); the eight loaded bytes stay as they are until the pixel's row needs them
+  unsigned int a_sel_rg, a_sel_b;
   {
     const unsigned int d_off = 2u * (unsigned int)colc;
     if (a.anchor_vec) {
@@ -381,7 +381,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       const unsigned int L = 3u * (unsigned int)colc;
       const unsigned int La = min(L & ~3u, 3u * (unsigned int)W - 8u);
       const unsigned int s = L - La;   // 0..5
-      a_sel = s | ((s + 1u) << 8) | ((s + 2u) << 16) | 0x0c000000u;
+      a_sel_rg = s | ((s + 1u) << 16) | 0x0c000c00u;
+      a_sel_b = (s + 2u) | 0x0c0c0c00u;
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         // (32-bit row offsets: an image has at most 2^29 pixels; scalar base + per-lane 32-bit offset)
@@ -396,7 +397,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       }
     } else {
       const unsigned int c_off = 3u * (unsigned int)colc;
-      a_sel = 0x0c020100u;
+      a_sel_rg = 0x0c010c00u;
+      a_sel_b = 0x0c0c0c02u;
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;
@@ -597,9 +599,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     // a tap (du, dv) is in the window when du < lim_u and dv < lim_v (unsigned compares)
     const unsigned int lim_u = (unsigned int)max(chunks_x * CHUNK - 1, 0), lim_v = (unsigned int)max(nrows - 1, 0);
 
-    Acc acc = {0.f, 0.f, 0.f, 0.f};
+    Acc acc = {0.f, 0.f, 0.0, 0.0};
     unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_fast = 0;
-    unsigned int c_geo = 0u;       // per lane: pixels with four non-zero depth taps (summed over the wave at the end)
+    unsigned int n_geo = 0u;       // pixels with four non-zero depth taps (counted from the lane masks)
     unsigned int rest_bits = 0u;   // bit r: row r of this lane is left to phase 2
 
     PairConsts pc;
@@ -610,13 +612,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     // (the anchors and row masks are made opaque to the optimiser once per neighbour: otherwise everything
     // that depends on them alone is computed for all rows ahead of the neighbour loop and held in registers;
     // here, after the staging, so that the anchor loads stay in flight behind the prediction and the staging)
-    unsigned int sel = a_sel;
-    asm volatile("" : "+v"(sel));   // (keeps the byte shuffles below, and with them the wait for the anchor loads, at this point)
+    unsigned int sel_rg = a_sel_rg, sel_b = a_sel_b;
+    asm volatile("" : "+v"(sel_rg), "+v"(sel_b));
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) {
-      a_rgb[r] = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel);
-      asm volatile("" : "+v"(a_d[r]), "+v"(a_rgb[r]));
-    }
+    for (int r = 0; r < RPW; ++r) asm volatile("" : "+v"(a_d[r]), "+v"(a_q[r].x), "+v"(a_q[r].y));
     asm volatile("" : "+s"(rows_nz), "+s"(rows_in));
     // columns of this wave inside the image, and of those the ones with col - cx != 0 (made here, at their use:
     // held from the kernel's start the two masks are parked in vector lanes across the staging)
@@ -694,20 +693,19 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
         return o;
       };
-      // (byte selectors of the anchor colour in scalar registers: as literals they are moved into a vector
-      // register again in every row)
-      unsigned int sel_rg = 0x0c010c00u, sel_b = 0x0c0c0c02u;
-      asm volatile("" : "+s"(sel_rg), "+s"(sel_b));
       Row cur = project_row(0);
 #pragma unroll
       for (int r = 0; r < RPW; ++r) {
         Row nxt = cur;
         if (r + 1 < RPW) nxt = project_row(r + 1);
+        // (evaluated on every lane, whatever its cells hold: the mask and its count are scalar work)
+        const unsigned long long m_geo = cur.m_fast & __builtin_amdgcn_ballot_w64(taps_nonzero(cur.t));
+        n_geo += (unsigned int)__popcll(m_geo);
         if (__builtin_amdgcn_inverse_ballot_w64(cur.m_fast)) {
-          const unsigned int argb = a_rgb[r];
-          const unsigned int a_rg = __builtin_amdgcn_perm(0u, argb, sel_rg);
-          const unsigned int a_b = __builtin_amdgcn_perm(0u, argb, sel_b);
-          blend_accumulate<UNIT>(acc, c_geo, cur.t, cur.fu, cur.fv, inv_factor_f, a_rg, a_b, cur.Z);
+          const unsigned int a_rg = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel_rg);
+          const unsigned int a_b = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel_b);
+          blend_accumulate<UNIT>(acc, __builtin_amdgcn_inverse_ballot_w64(m_geo), cur.t, cur.fu, cur.fv, inv_factor_f,
+                                 a_rg, a_b, cur.Z);
         }
         cur = nxt;
         __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead: more only lengthens live ranges
@@ -746,7 +744,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       for (int r = 0; r < RPW; ++r) {
         const bool need = (rest_bits >> r) & 1u;
         if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-        bool valid0 = false, inb = false, wv = false;
+        bool valid0 = false, inb = false, wv = false, geo = false;
         if (need) {
           const int row = row0 + r;
           const long long o = (long long)row * W + col;
@@ -776,12 +774,14 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
             const unsigned int rgbx = (unsigned int)cp[0] | ((unsigned int)cp[1] << 8) | ((unsigned int)cp[2] << 16);
             const unsigned int a_rg = __builtin_amdgcn_perm(0u, rgbx, 0x0c010c00u);
             const unsigned int a_b = __builtin_amdgcn_perm(0u, rgbx, 0x0c0c0c02u);
-            blend_accumulate<UNIT>(acc, c_geo, t, fu, fv, inv_factor_f, a_rg, a_b, z2);
+            geo = taps_nonzero(t);
+            blend_accumulate<UNIT>(acc, geo, t, fu, fv, inv_factor_f, a_rg, a_b, z2);
           }
         }
         n_valid0 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(valid0));
         n_inb += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(inb));
         n_warp += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(wv));
+        n_geo += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(geo));
       }
     }
 
@@ -790,8 +790,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     // (64 lanes adding to one LDS word serialise in the LDS pipe and stall the
     // wave far longer than the 6 DPP steps cost)
     const float t0 = wave_sum63(acc.ap) * COLOUR_UNSCALE, t1 = wave_sum63(acc.sp) * (COLOUR_UNSCALE * COLOUR_UNSCALE);
-    const float t2s = wave_sum63(acc.ag), t3 = wave_sum63(acc.sg);
-    const unsigned int n_geo = wave_isum63(c_geo);
+    const float t2s = wave_sum63((float)acc.ag), t3 = wave_sum63((float)acc.sg);
     if (lane == 63) {
       s_sum[wave][0] = t0; s_sum[wave][1] = t1; s_sum[wave][2] = t2s; s_sum[wave][3] = t3;
       s_cnt[wave][0] = n_valid0 + n_fast; s_cnt[wave][1] = n_inb + n_fast; s_cnt[wave][2] = n_warp + n_fast; s_cnt[wave][3] = n_geo;
