@@ -55,6 +55,16 @@ constexpr int CHUNK = 8;                        // staging granule in pixels (16
 constexpr int WIN_PITCH = 160;                  // LDS window row pitch in cells (multiple of CHUNK)
 // window rows for a tile of th rows: th + 8, one less where that lets four workgroups share a CU's 160 KiB
 constexpr int win_rows(int th) { return th == 24 ? 31 : th + 8; }
+// Staging rounds of a workgroup of tpb threads: with cx chunks per window row a round covers tpb / cx whole rows
+// (thread t keeps chunk column t % cx in every round), so `rows` rows take at most this many rounds for any cx.
+constexpr int stage_rounds(int tpb, int rows) {
+  int m = 1;
+  for (int cx = 1; cx <= WIN_PITCH / CHUNK; ++cx) {
+    const int rpp = tpb / cx, n = (rows + rpp - 1) / rpp;
+    if (n > m) m = n;
+  }
+  return m;
+}
 
 // workspace record of one (image, neighbour) pair: 64 bytes
 struct PairAcc {
@@ -312,7 +322,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
   static_assert(RPW >= 1 && RPW <= 32, "one bit per row in a 32-bit mask");
   __shared__ uint2 win[WIN_PITCH * WIN_ROWS];
   __shared__ unsigned int s_rng[NW][2];
-  __shared__ int s_winrec[4];
+  __shared__ int s_winrec[6];
   __shared__ float s_sum[NW][4];
   __shared__ unsigned int s_cnt[NW][4];
   __shared__ PairConsts s_pc;
@@ -523,7 +533,14 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
           if (ncols < 2 || nrows < 2) ncols = nrows = 0;   // a tap needs two columns and two rows
         }
       }
-      if (lane == 0) { s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows; }
+      // chunks per window row, its 16-bit reciprocal (t / cx = (t * inv) >> 16, exact for t < 2^16 / cx) and the
+      // whole rows a staging round covers: made here once instead of by every wave after the barrier
+      const unsigned int cxs = (unsigned int)(ncols + CHUNK - 1) / CHUNK;
+      const unsigned int inv = cxs ? 65535u / cxs + 1u : 0u;
+      if (lane == 0) {
+        s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows;
+        s_winrec[4] = (int)inv; s_winrec[5] = (int)(((unsigned int)TPB * inv) >> 16);
+      }
     }
     if constexpr (K1) {
       if (wave == 1) {
@@ -538,15 +555,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     const int ncols = __builtin_amdgcn_readfirstlane(s_winrec[2]), nrows = __builtin_amdgcn_readfirstlane(s_winrec[3]);
 
     // ---- stage the window: 8-byte cells {half R | half G, half B | raw depth} ----
+    // A thread keeps one chunk column (8 pixels) and walks down the window: round q holds rows q * rpp .. + rpp - 1,
+    // thread t the chunk (q * rpp + t / chunks_x, t % chunks_x).  Source and destination then advance by a
+    // wave-uniform step per round: per-thread 32-bit offsets are made once and the planes' bases move in scalar
+    // registers (a chunk's address costs no vector instruction after the first round).
     const int chunks_x = (ncols + CHUNK - 1) / CHUNK;
-    const int nchunks = chunks_x * nrows;
-    // chunk c -> (row, chunk in row) by a 16-bit reciprocal: exact for c < 2^16 / chunks_x
-    const unsigned int inv_cx = chunks_x ? (65535u / (unsigned int)chunks_x + 1u) : 0u;
-    auto chunk_src = [&](int c, uint2*& dst) -> int {
-      const int cr = (int)(((unsigned int)c * inv_cx) >> 16), cc = c - cr * chunks_x;
-      dst = win + cr * WIN_PITCH + cc * CHUNK;
-      return (wy0 + cr) * W + wx0 + cc * CHUNK;   // inside the image, 8-pixel aligned
-    };
+    const unsigned int inv_cx = (unsigned int)__builtin_amdgcn_readfirstlane(s_winrec[4]);
+    const int rpp = __builtin_amdgcn_readfirstlane(s_winrec[5]);
     auto chunk_store = [&](uint2* dst, const uint4 dv, const uint2 q0, const uint2 q1, const uint2 q2) {
       const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w};
       const uint32_t cw[7] = {q0.x, q0.y, q1.x, q1.y, q2.x, q2.y, 0u};
@@ -569,27 +584,40 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       }
     };
     // one pass: every thread has the loads of all its chunks in flight before it converts the first
-    constexpr int NQ = (WIN_PITCH / CHUNK * WIN_ROWS + TPB - 1) / TPB;   // chunks per thread at most
+    constexpr int NQ = stage_rounds(TPB, WIN_ROWS);
 #ifndef SLAMHIP_ABL_NO_STAGE      // (timing ablation only: results are wrong without the staging)
-    if (nchunks > 0) {
-      uint2* dst[NQ];
+    if (chunks_x > 0 && nrows > 0) {
+      const unsigned int cr0 = ((unsigned int)tid * inv_cx) >> 16, cc = (unsigned int)tid - cr0 * (unsigned int)chunks_x;
+      const bool mine = cr0 < (unsigned int)rpp;      // (the last tpb % chunks_x threads have no chunk)
+      const unsigned int wave_r0 = ((unsigned int)(wave * 64) * inv_cx) >> 16;   // first window row of this wave's chunks
+      // pixel offset of the thread's chunk in round 0 (inside the image, 8-pixel aligned; 32 bits: an image has at most 2^29 pixels)
+      const unsigned int pix0 = (unsigned int)(wy0 + (int)cr0) * (unsigned int)W + (unsigned int)wx0 + cc * CHUNK;
+      const unsigned int d_off = 2u * pix0, c_off = 3u * pix0;
+      uint2* const dst0 = win + cr0 * WIN_PITCH + cc * CHUNK;
+      const unsigned int rstep = (unsigned int)rpp * (unsigned int)W;   // pixels per round
       uint4 dvq[NQ];
       uint2 cq[NQ][3];
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
-        if (q > 0 && q * TPB + wave * 64 >= nchunks) continue;   // (wave-uniform) none of this wave's chunks of this round exists
-        const int c = tid + q * TPB;
-        const int o = chunk_src(c < nchunks ? c : 0, dst[q]);
-        dvq[q] = *reinterpret_cast<const uint4*>(d2 + o);
-        const uint2* cp = reinterpret_cast<const uint2*>(c2 + 3 * o);
-        cq[q][0] = cp[0]; cq[q][1] = cp[1]; cq[q][2] = cp[2];
+        if ((int)wave_r0 + q * rpp >= nrows) continue;   // (wave-uniform) none of this wave's chunks of this round exists
+        if (mine && (int)cr0 + q * rpp < nrows) {
+          const char* dq = reinterpret_cast<const char*>(d2) + (size_t)(2u * rstep * (unsigned int)q);
+          const char* cqp = reinterpret_cast<const char*>(c2) + (size_t)(3u * rstep * (unsigned int)q);
+          dvq[q] = *reinterpret_cast<const uint4*>(dq + d_off);
+          const uint2* cp = reinterpret_cast<const uint2*>(cqp + c_off);
+          cq[q][0] = cp[0]; cq[q][1] = cp[1]; cq[q][2] = cp[2];
+        }
       }
       SLAMHIP_STAMP(4);   // staging loads issued
+#ifdef SLAMHIP_STAMPS
       asm volatile("s_waitcnt vmcnt(0)");
+#endif
       SLAMHIP_STAMP(5);   // ... and landed (diagnostic builds only wait here for all of them)
 #pragma unroll
-      for (int q = 0; q < NQ; ++q)
-        if (tid + q * TPB < nchunks) chunk_store(dst[q], dvq[q], cq[q][0], cq[q][1], cq[q][2]);
+      for (int q = 0; q < NQ; ++q) {
+        if ((int)wave_r0 + q * rpp >= nrows) continue;
+        if (mine && (int)cr0 + q * rpp < nrows) chunk_store(dst0 + q * rpp * WIN_PITCH, dvq[q], cq[q][0], cq[q][1], cq[q][2]);
+      }
     }
 #endif
     SLAMHIP_STAMP(6);   // cells written
