@@ -113,7 +113,7 @@ int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double d
 /* ---- device: fused frame-pair kernel (the benchmarked path) --------------- */
 
 /* Bytes of workspace slamhip_pair_loss_fused needs for a batch of B anchors with
- * k neighbours each (64 bytes per pair).  No counterpart in the reference. */
+ * k neighbours each (128 bytes per pair).  No counterpart in the reference. */
 size_t slamhip_pair_loss_workspace_bytes(int B, int k);
 
 /* test_import.py:148-176 + bilinear warp + residual reduction, nothing
@@ -144,7 +144,7 @@ int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, v
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): it has no
  * counterpart in the reference.  Same inputs, outputs and arithmetic, no workspace
  * argument: the accumulator records live in a device array built into the library
- * (SLAMHIP_STATIC_MAX_PAIRS records of 64 bytes on every GPU the library runs on, held
+ * (SLAMHIP_STATIC_MAX_PAIRS records of 128 bytes on every GPU the library runs on, held
  * until the process ends), which the call clears on `stream` before the launch (with a kernel:
  * a captured call holds kernel nodes only).  It
  * calls no hipMalloc / hipFree.  B * k beyond SLAMHIP_STATIC_MAX_PAIRS is rejected with

@@ -66,14 +66,18 @@ constexpr int stage_rounds(int tpb, int rows) {
   return m;
 }
 
-// workspace record of one (image, neighbour) pair: 64 bytes
+// workspace record of one (image, neighbour) pair: 128 bytes.  The counts are accumulated as float64 like the
+// sums (exact below 2^53), so that a workgroup adds all eight values with ONE atomic instruction: what a
+// workgroup pays at its end is the wait for its atomics before it draws its ticket, and two instructions to the
+// record's line take 1.7 us longer per 64-pair launch than one.  (Drawing the ticket as a ninth lane of that
+// instruction, with a second counter that tells the publishing workgroup when every add has been performed, is
+// no faster: 65.6 against 65.1 us.)
 struct PairAcc {
-  double sums[SLAMHIP_NSUMS];
-  unsigned int counts[SLAMHIP_NCOUNTS];
+  double vals[SLAMHIP_NSUMS + SLAMHIP_NCOUNTS];   // sums, then counts
   unsigned int ticket;
-  unsigned int pad[3];
+  unsigned int pad[15];
 };
-static_assert(sizeof(PairAcc) == 64, "PairAcc must stay 64 bytes");
+static_assert(sizeof(PairAcc) == 128, "PairAcc must stay 128 bytes");
 
 struct FusedArgs {   // everything but the pointers (those are __restrict__ kernel parameters of their own)
   Cam cam;
@@ -420,6 +424,8 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       }
     }
   }
+  // (wave 0 asking for its anchors only behind its staging loads, so that it can start on the window prediction
+  // at once, gives the anchor registers two definition sites: 128 vector registers and 212 bytes of scratch)
   SLAMHIP_STAMP(1);   // anchor loads issued
   const float factor_f = (float)cam.factor;
   const float inv_factor_f = 1.0f / factor_f;
@@ -507,6 +513,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       have_range = true;
     }
     if (wave == 0) {
+      __builtin_amdgcn_s_setprio(3);   // the other waves of the workgroup wait for this one (0.7-0.9 us per launch)
       const unsigned int z_near = depth_free ? 256u : zmn, z_far = depth_free ? 65535u : zmx;
       const bool any_depth = depth_free || zmx != 0u;
       int wx0 = 0, wy0 = 0, ncols = 0, nrows = 0;
@@ -541,6 +548,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         s_winrec[0] = wx0; s_winrec[1] = wy0; s_winrec[2] = ncols; s_winrec[3] = nrows;
         s_winrec[4] = (int)inv; s_winrec[5] = (int)(((unsigned int)TPB * inv) >> 16);
       }
+      __builtin_amdgcn_s_setprio(0);
     }
     if constexpr (K1) {
       if (wave == 1) {
@@ -845,15 +853,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         counts_out = q->counts;
         last_ticket = (unsigned int)(q->a.tiles_x * q->a.tiles_y) - 1u;
       }
-      if (pl < 4) {
-        double t = (double)s_sum[0][pl] + (double)s_sum[1][pl];
-        if (NW == 4) t += (double)s_sum[2][pl] + (double)s_sum[3][pl];
-        atomicAdd(&pa->sums[pl], t);
-      } else if (pl < 8) {
-        const int q = (int)pl - 4;
+      if (pl < 8) {
+        const int q = (int)pl & 3;
+        double t = (double)s_sum[0][q] + (double)s_sum[1][q];
+        if (NW == 4) t += (double)s_sum[2][q] + (double)s_sum[3][q];
         unsigned int c = s_cnt[0][q] + s_cnt[1][q];
         if (NW == 4) c += s_cnt[2][q] + s_cnt[3][q];
-        atomicAdd(&pa->counts[q], c);
+        atomicAdd(&pa->vals[pl], pl < 4 ? t : (double)c);
       }
 #ifdef SLAMHIP_ABL_NO_TICKET     // timing ablation only: nothing is published
       continue;
@@ -865,9 +871,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       t = __builtin_amdgcn_readfirstlane(t);
       if (t == last_ticket) {
         // last workgroup of this pair: totals out, accumulators back to zero
-        if (pl < 4) sums_out[bjo * SLAMHIP_NSUMS + pl] = atomicExch(&pa->sums[pl], 0.0);
-        else if (pl < 8) counts_out[bjo * SLAMHIP_NCOUNTS + (pl - 4)] = atomicExch(&pa->counts[pl - 4], 0u);
-        else if (pl == 8) atomicExch(&pa->ticket, 0u);
+        if (pl < 8) {
+          const double v = atomicExch(&pa->vals[pl], 0.0);
+          if (pl < 4) sums_out[bjo * SLAMHIP_NSUMS + pl] = v;
+          else counts_out[bjo * SLAMHIP_NCOUNTS + (pl - 4)] = (unsigned int)v;
+        } else if (pl == 8) {
+          atomicExch(&pa->ticket, 0u);
+        }
       }
       SLAMHIP_STAMP(11);  // ticket drawn
 #ifdef SLAMHIP_STAMPS
@@ -881,7 +891,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Clears accumulator records with a kernel (a record is 64 bytes, four 16-byte stores): callers may record
+// Clears accumulator records with a kernel (a record is 128 bytes, eight 16-byte stores): callers may record
 // these entry points in a HIP graph, where a memset becomes a node of its own kind; kernel nodes alone
 // replay in order.
 __global__ void __launch_bounds__(256) clear_records_kernel(uint4* __restrict__ p, size_t n16) {

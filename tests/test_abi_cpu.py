@@ -78,8 +78,8 @@ def test_version_and_error_text():
         rc = lib.slamhip_pair_loss_fused(a16, a16, a16, a16, a16, capi.K4([500, 500, 64, 12]), 1.0, B, k, H, 128,
                                          a16, a16, a16, need, None)
         assert rc == -3 and b"grid too large" in lib.slamhip_last_error(), (B, k, H, rc, lib.slamhip_last_error())
-    assert lib.slamhip_pair_loss_workspace_bytes(64, 1) == 64 * 64
-    assert lib.slamhip_pair_loss_workspace_bytes(3, 4) == 3 * 4 * 64
+    assert lib.slamhip_pair_loss_workspace_bytes(64, 1) == 64 * 128
+    assert lib.slamhip_pair_loss_workspace_bytes(3, 4) == 3 * 4 * 128
 
 
 def test_host_pose_entry_points_against_reference_golden(golden_dir):
