@@ -45,8 +45,8 @@ namespace slamhip {
 //      so the prediction never affects results.
 // Predicates are 64-bit lane masks in scalar registers (one vector compare each,
 // combined and counted on the scalar unit).  Reduction: sums by DPP row reductions,
-// the four waves through LDS, then one float64 / uint32 atomic per quantity per
-// workgroup into the accumulators of the caller's workspace.  The workgroup that draws
+// the four waves through LDS, then one float64 atomic instruction per workgroup (eight lanes:
+// the four sums and the four counts) into the accumulators of the caller's workspace.  The workgroup that draws
 // the last ticket of an (image, neighbour) pair moves the totals to the outputs with
 // atomic exchanges, which also leaves the workspace zeroed for the next call: no memset
 // and no second kernel on the stream.
@@ -924,7 +924,7 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
   // One workgroup per tile of one (anchor, neighbour) pair, 128 x 24 pixels on four waves: that kernel is
-  // straight-line code (no loop over neighbours), needs 89 vector registers and 39 KB of LDS, and four
+  // straight-line code (no loop over neighbours), needs 99 vector registers and 39 KB of LDS, and four
   // workgroups share a compute unit.  The form that walks an anchor's k neighbours in one workgroup and reads the
   // anchor tile once (168 registers, 128 x 32 tiles, three workgroups per compute unit) is slower although it
   // reads less - the kernel is bound by vector instructions, and the k pairs of an anchor tile run back to
