@@ -256,6 +256,19 @@ int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* su
                              const float* beta, float* red2c, void* dz, int B, int H, int W, int C,
                              float eps, void* stream);
 
+/* The two backward calls with their passes apart, for normalisation statistics kept over several
+ * data-parallel ranks (the reference is single-device: cnn_model.py:100-113 normalises over the
+ * one batch it sees; one batch spread over N ranks gives the same numbers only if the sums do).
+ * phases bit 0: the reduction pass (writes red2c, dz may be NULL); bit 1: the pass that writes dz
+ * from red2c.  Between the two the caller averages red2c over the ranks, and sums2c after the
+ * forward's statistics; every rank passes its own row count.  phases = 3 is the plain call. */
+int slamhip_bn_relu_bwd_phases(const void* dy, const void* z, const float* sums2c, const float* gamma,
+                               const float* beta, float* red2c, void* dz, long long P, int C, float eps,
+                               int phases, void* stream);
+int slamhip_bn_relu_pool_bwd_phases(const void* dpooled, const void* z, const float* sums2c,
+                                    const float* gamma, const float* beta, float* red2c, void* dz, int B,
+                                    int H, int W, int C, float eps, int phases, void* stream);
+
 /* cnn_model.py:123,74 / cnn_model_noBN.py (bias_add + relu) - y = act(z + bias) on a float32
  * [M][N] product (relu=0: the linear output layer); backward: dz = dy * (y>0),
  * dbias[n] = sum_m dz. */

@@ -64,6 +64,8 @@ SIGNATURES = {
     "slamhip_bn_relu_bwd": ([_c_void_p] * 7 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p], _c_int),
     "slamhip_bn_relu_pool_fwd": ([_c_void_p] * 6 + [_c_int] * 4 + [ctypes.c_float, _c_void_p], _c_int),
     "slamhip_bn_relu_pool_bwd": ([_c_void_p] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_void_p], _c_int),
+    "slamhip_bn_relu_bwd_phases": ([_c_void_p] * 7 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_int, _c_void_p], _c_int),
+    "slamhip_bn_relu_pool_bwd_phases": ([_c_void_p] * 7 + [_c_int] * 4 + [ctypes.c_float, _c_int, _c_void_p], _c_int),
     "slamhip_bias_act_fwd": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
     "slamhip_bias_act_bwd": ([_c_void_p] * 4 + [_c_int] * 3 + [_c_void_p], _c_int),
     "slamhip_maxpool2_fwd": ([_c_void_p] * 2 + [_c_int] * 4 + [_c_void_p], _c_int),

@@ -2335,21 +2335,35 @@ int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, 
   return SLAMHIP_OK;
 }
 
-int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, const float* gamma, const float* beta,
-                        float* red2c, void* dz, long long P, int C, float eps, void* stream) {
-  SLAMHIP_REQUIRE(dy && z && sums2c && gamma && beta && red2c && dz && P > 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG,
-                  "bn_relu_bwd: bad argument");
+// phases: bit 0 = the reduction pass (red2c), bit 1 = the pass that writes dz from red2c.  A caller that keeps
+// the normalisation statistics over several ranks runs the two passes apart and averages red2c over the
+// ranks in between (sums2c averaged the same way after the forward's statistics).
+int slamhip_bn_relu_bwd_phases(const void* dy, const void* z, const float* sums2c, const float* gamma,
+                               const float* beta, float* red2c, void* dz, long long P, int C, float eps, int phases,
+                               void* stream) {
+  SLAMHIP_REQUIRE(dy && z && sums2c && gamma && beta && red2c && (dz || !(phases & 2)) && P > 0 && C > 0 &&
+                      C % 64 == 0 && (phases & 3) && !(phases & ~3),
+                  SLAMHIP_E_ARG, "bn_relu_bwd: bad argument");
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_bwd: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
-  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
-  const long long total8 = P * C / 8;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+  if (phases & 1) {
+    SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
+                       (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
+  }
+  if (phases & 2) {
+    const long long total8 = P * C / 8;
+    hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s, (const bf16*)dy,
+                       (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, C, 1.0f / (float)P, eps);
+  }
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_bwd(const void* dy, const void* z, const float* sums2c, const float* gamma, const float* beta,
+                        float* red2c, void* dz, long long P, int C, float eps, void* stream) {
+  return slamhip_bn_relu_bwd_phases(dy, z, sums2c, gamma, beta, red2c, dz, P, C, eps, 3, stream);
 }
 
 int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* sums2c, const float* gamma,
@@ -2385,24 +2399,35 @@ int slamhip_bn_relu_pool_fwd(const void* z, const float* sums2c, const float* ga
   return SLAMHIP_OK;
 }
 
-int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* sums2c, const float* gamma,
-                             const float* beta, float* red2c, void* dz, int B, int H, int W, int C, float eps,
-                             void* stream) {
-  SLAMHIP_REQUIRE(dpooled && z && sums2c && gamma && beta && red2c && dz && B > 0 && H > 0 && W > 0 && H % 2 == 0 &&
-                      W % 2 == 0 && C > 0 && C % 64 == 0 && C <= 2048,
+int slamhip_bn_relu_pool_bwd_phases(const void* dpooled, const void* z, const float* sums2c, const float* gamma,
+                                    const float* beta, float* red2c, void* dz, int B, int H, int W, int C, float eps,
+                                    int phases, void* stream) {
+  SLAMHIP_REQUIRE(dpooled && z && sums2c && gamma && beta && red2c && (dz || !(phases & 2)) && B > 0 && H > 0 &&
+                      W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 64 == 0 && C <= 2048 && (phases & 3) &&
+                      !(phases & ~3),
                   SLAMHIP_E_ARG, "bn_relu_pool_bwd: bad argument (even height and width, channels % 64 == 0, <= 2048)");
   const long long P = (long long)B * H * W, PP = P / 4;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_pool_bwd: too many pixels");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
-  hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(reduce_grid(PP, C)), dim3(256), 0, s, (const bf16*)dpooled,
-                     (const bf16*)z, sums2c, gamma, beta, red2c, PP, H, W, C, 1.0f / (float)P, eps);
-  const long long total8 = PP * (C / 8);
-  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s,
-                     (const bf16*)dpooled, (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, H, W, C,
-                     1.0f / (float)P, eps);
+  if (phases & 1) {
+    SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
+    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(reduce_grid(PP, C)), dim3(256), 0, s, (const bf16*)dpooled,
+                       (const bf16*)z, sums2c, gamma, beta, red2c, PP, H, W, C, 1.0f / (float)P, eps);
+  }
+  if (phases & 2) {
+    const long long total8 = PP * (C / 8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(channel_stride_grid(total8, C)), dim3(256), 0, s,
+                       (const bf16*)dpooled, (const bf16*)z, sums2c, red2c, gamma, beta, (bf16*)dz, total8, H, W, C,
+                       1.0f / (float)P, eps);
+  }
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_pool_bwd(const void* dpooled, const void* z, const float* sums2c, const float* gamma,
+                             const float* beta, float* red2c, void* dz, int B, int H, int W, int C, float eps,
+                             void* stream) {
+  return slamhip_bn_relu_pool_bwd_phases(dpooled, z, sums2c, gamma, beta, red2c, dz, B, H, W, C, eps, 3, stream);
 }
 
 int slamhip_bias_act_fwd(const float* z, const float* bias, void* y_bf16, float* y_f32, int M, int N, int relu,

@@ -58,6 +58,24 @@ def total_pair_sums(sums, counts):
     return s, c
 
 
+_stats_group = None
+
+
+def average_over_ranks(t):
+    """t (a small float32 tensor of per-rank sums) -> its mean over the ranks, in place.  Used for the
+    batch-norm statistics kept over all ranks; runs on a process group of its own so that it does not
+    queue behind the gradient buckets' all-reduce on the default group.  Every rank must call it the same
+    number of times in the same order."""
+    global _stats_group
+    if not initialised() or world_size() == 1:
+        return t
+    if _stats_group is None:
+        _stats_group = dist.new_group()     # (collective: every rank gets here at its first statistics exchange)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=_stats_group)
+    t.mul_(1.0 / world_size())
+    return t
+
+
 def agree_min(value, device=None):
     """The smallest `value` (an int) over the ranks: every rank must run the same number of training
     steps, because every step issues the gradient all-reduces."""

@@ -21,6 +21,7 @@ import os
 import torch
 
 from . import encoder_ops as ops
+from .. import distributed as dp
 from .model_config import get_config_provider
 from ..utils.time_utils import time_it
 
@@ -119,14 +120,19 @@ class _Optimizer:
 class VGG16Model:
 
     def __init__(self, batch_size, rgbd_input_batch, output_dim, normalization_epsilon,
-                 initial_params=None, fc_dim=4096, seed=0, batch_norm=True):
+                 initial_params=None, fc_dim=4096, seed=0, batch_norm=True, sync_batch_norm=False):
         """rgbd_input_batch: float32 GPU tensor [batch, H, W, 4] that the caller refills in
         place before each step (the reference's placeholder, main/vgg16_rgbd.py:29).
         initial_params: optional {'conv1_2': {'weights': HWIO array, 'biases': ...}, ...}
         as the reference reads from its weights file (cnn_model.py:22-23, 129-137);
         layers without an entry (and conv1_1 always) start from a truncated normal.
         batch_norm=False gives the variant of slam/network/cnn_model_noBN.py:90-111:
-        conv -> bias -> ReLU instead of conv -> batch-norm -> ReLU."""
+        conv -> bias -> ReLU instead of conv -> batch-norm -> ReLU.
+        sync_batch_norm: under torch.distributed the normalisation uses the statistics of the whole
+        job's batch (the per-channel sums of the forward and of the backward reduction are averaged over
+        the ranks), so that N ranks with batch b compute what one device computes on batch N * b, which
+        is what the reference's single-device graph means by "the batch" (cnn_model.py:100-113).  Off
+        (the default) every rank normalises over its own batch and no collective runs in the passes."""
         if not (rgbd_input_batch.is_cuda and rgbd_input_batch.dtype == torch.float32
                 and rgbd_input_batch.dim() == 4 and rgbd_input_batch.shape[0] == batch_size):
             raise ValueError("rgbd_input_batch must be a float32 GPU tensor [batch, H, W, C]")
@@ -142,6 +148,7 @@ class VGG16Model:
         self.initial_params = initial_params or {}
         self.fc_dim = int(fc_dim)
         self.batch_norm = bool(batch_norm)
+        self.sync_batch_norm = bool(sync_batch_norm)
         self.seed = seed
         self.total_weights = 0
         self.device = rgbd_input_batch.device
@@ -356,6 +363,10 @@ class VGG16Model:
             self._refresh_operands()
             self._operands_stale = True
 
+    def _sync_stats(self):
+        """The normalisation statistics are exchanged between the ranks in this pass."""
+        return self.sync_batch_norm and dp.initialised() and dp.world_size() > 1
+
     def _refresh_operands(self):
         for a in self._act[1:]:
             n = a["name"]
@@ -382,6 +393,10 @@ class VGG16Model:
                     ops.conv3x3_small_stats(h, self.params[n + "/weights"], a["z"], a["sums"], self._stats_ws)
                 else:
                     ops.conv3x3_stats(h, self._w_fwd[n], a["z"], a["sums"], self._stats_ws)
+                if self._sync_stats():
+                    # equal row counts on every rank: the mean of the ranks' sums over one rank's row count is
+                    # the whole batch's mean (and mean square)
+                    dp.average_over_ranks(a["sums"])
                 bn = self.params[n + "/bn"]
                 if a["pool"]:       # normalisation, ReLU and the block's max-pool in one pass
                     # the full-resolution y of a pooled layer has no reader (the next layer takes the
@@ -480,8 +495,9 @@ class VGG16Model:
             n = a["name"]
             g_out = g.clone() if self.trace is not None else None
             dz = self._buf(("dz", a["z"].shape), a["z"])
+            sync = self.batch_norm and self._sync_stats()
             if (i == 0 and self.fuse_first_backward and self.batch_norm and not a["pool"] and self.trace is None
-                    and a["z"].shape[-1] == 64 and self._x.shape[-1] == 4):
+                    and a["z"].shape[-1] == 64 and self._x.shape[-1] == 4 and not sync):
                 # first layer: its dz has one reader, the filter gradient, which computes it on the way
                 bn = self.params[n + "/bn"]
                 ops.bn_relu_bwd_first_layer(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], self._x,
@@ -489,10 +505,14 @@ class VGG16Model:
                 continue
             if self.batch_norm:
                 bn = self.params[n + "/bn"]
-                if a["pool"]:   # pool backward + ReLU gate + batch-norm backward, no upsampled gradient tensor
-                    ops.bn_relu_pool_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
+                bwd = ops.bn_relu_pool_bwd if a["pool"] else ops.bn_relu_bwd
+                # (pooled layers: pool backward + ReLU gate + batch-norm backward, no upsampled gradient tensor)
+                if sync:    # the two reduced sums of the whole batch: reduce, average over the ranks, apply
+                    bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon, phases=1)
+                    dp.average_over_ranks(self.grads[n + "/bn"])
+                    bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon, phases=2)
                 else:
-                    ops.bn_relu_bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
+                    bwd(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], dz, self.epsilon)
             else:
                 if a["pool"]:
                     dy = self._buf(("dy", a["y"].shape), a["y"])

@@ -108,16 +108,18 @@ def bn_relu(z, sums2c, gamma, beta, y, eps):
           float(eps))
 
 
-def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps):
-    """dz, and red2c[0] = dbeta, red2c[1] = dgamma.  The ReLU gate is recomputed from z."""
+def bn_relu_bwd(dy, z, sums2c, gamma, beta, red2c, dz, eps, phases=3):
+    """dz, and red2c[0] = dbeta, red2c[1] = dgamma.  The ReLU gate is recomputed from z.
+    phases: 1 = the reduction pass alone (red2c), 2 = the pass that writes dz from red2c, 3 = both
+    (statistics kept over several ranks: red2c is averaged over the ranks between the two)."""
     C = _chk(z, BF16, "z").shape[-1]
     P = z.numel() // C
     for t in (dy, dz):
         assert _chk(t, BF16, "bn tensor").shape == z.shape
     assert _chk(red2c, F32, "red").shape == (2, C) and sums2c.shape == (2, C)
     assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
-    _call("slamhip_bn_relu_bwd", capi.ptr(dy), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta),
-          capi.ptr(red2c), capi.ptr(dz), P, C, float(eps))
+    _call("slamhip_bn_relu_bwd_phases", capi.ptr(dy), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta),
+          capi.ptr(red2c), capi.ptr(dz), P, C, float(eps), int(phases))
 
 
 def bn_relu_bwd_first_layer(dy, z, sums2c, gamma, beta, red2c, x, dw, eps):
@@ -145,16 +147,16 @@ def bn_relu_pool(z, sums2c, gamma, beta, y, pooled, eps):
           capi.ptr(pooled), B, H, W, C, float(eps))
 
 
-def bn_relu_pool_bwd(dpooled, z, sums2c, gamma, beta, red2c, dz, eps):
+def bn_relu_pool_bwd(dpooled, z, sums2c, gamma, beta, red2c, dz, eps, phases=3):
     """Max-pool backward, ReLU gate and batch-norm backward in one step: the pooled gradient
-    [B,H/2,W/2,C] -> dz (like z); red2c as bn_relu_bwd."""
+    [B,H/2,W/2,C] -> dz (like z); red2c and phases as bn_relu_bwd."""
     B, H, W, C = _chk(z, BF16, "z").shape
     assert H % 2 == 0 and W % 2 == 0 and C % 64 == 0
     assert _chk(dpooled, BF16, "dpooled").shape == (B, H // 2, W // 2, C) and _chk(dz, BF16, "dz").shape == z.shape
     assert _chk(red2c, F32, "red").shape == (2, C) and _chk(sums2c, F32, "sums").shape == (2, C)
     assert _chk(gamma, F32, "gamma").shape == (C,) and _chk(beta, F32, "beta").shape == (C,)
-    _call("slamhip_bn_relu_pool_bwd", capi.ptr(dpooled), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma), capi.ptr(beta),
-          capi.ptr(red2c), capi.ptr(dz), B, H, W, C, float(eps))
+    _call("slamhip_bn_relu_pool_bwd_phases", capi.ptr(dpooled), capi.ptr(z), capi.ptr(sums2c), capi.ptr(gamma),
+          capi.ptr(beta), capi.ptr(red2c), capi.ptr(dz), B, H, W, C, float(eps), int(phases))
 
 
 def bias_act(z, bias, y_bf16=None, y_f32=None, relu=True):
