@@ -37,6 +37,9 @@ def main(argv=None, model_class=VGG16Model):
                     help="upload raw frames and do depth scaling, resize and mean subtraction on the GPU")
     ap.add_argument("--max-steps", type=int, default=0, help="stop after this many training steps (0 = no limit)")
     ap.add_argument("--epochs", type=int, default=0, help="override the configured number of epochs")
+    ap.add_argument("--sync-batch-norm", action="store_true",
+                    help="under torch.distributed: normalise over the whole job's batch (statistics averaged over the "
+                         "ranks) instead of each rank's own")
     a = ap.parse_args(argv)
 
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
@@ -73,6 +76,7 @@ def main(argv=None, model_class=VGG16Model):
     loss_weight = torch.zeros(6, 6, dtype=torch.float32, device=dev)
 
     vgg_model = model_class(batch_size, rgbd_input_batch, 6, normalization_epsilon)
+    vgg_model.sync_batch_norm = bool(a.sync_batch_norm)
     vgg_model.build_graph()
     loss = vgg_model.add_loss(loss_weight, groundtruth_batch)
     apply_gradient_op = vgg_model.add_optimizer()
