@@ -224,8 +224,16 @@ def main():
     for i in range(a.warmup):
         step(i)
     torch.cuda.synchronize()
+    post_barrier_launches = 0
     if dist is not None:
         dist.barrier()
+        torch.cuda.synchronize()
+        # the barrier leaves the GPU idle for as long as the ranks take to meet, and the shader clock falls back
+        # within that time (measured: 71 us per launch in the 20 steps after it against 65 us before; 300 launches bring back most of it, 1500 all): the same
+        # number of untimed launches on every rank brings it back before the timed steps
+        post_barrier_launches = int(os.environ.get("BENCH_POST_BARRIER_LAUNCHES", "1500"))
+        for i in range(post_barrier_launches):
+            step(i)
     torch.cuda.synchronize()
     # one HIP event pair brackets the K launches on the stream they run on: the
     # launches are back to back, so elapsed / K is the kernel's average duration
@@ -346,7 +354,7 @@ def main():
                                    % ("configs[1]: " if (k, H, W) == (1, 480, 640) else "", W, H, B, k,
                                       "" if k == 1 else "s", a.depth, a.factor),
                        "pairs_per_gpu_per_step": B * k, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world,
-                       "streams": max(1, a.streams), "ramp_ms": a.ramp_ms, "ramp_launches": ramp_launches},
+                       "streams": max(1, a.streams), "ramp_ms": a.ramp_ms, "ramp_launches": ramp_launches, "post_barrier_launches": post_barrier_launches},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes per launch",
                          "traffic_source": traffic_src,
