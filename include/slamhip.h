@@ -110,6 +110,16 @@ int slamhip_reproject(const void* xyz, int xyz_f64, const uint8_t* valid0, const
 int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double dim_v, uint8_t* mask,
                           uint32_t* count, void* stream);
 
+/* test_import.py:148-176 as the frame dropping of _get_data calls it (:204-214), in one pass
+ * over the anchor's depth plane: depth uint16 [B,H,W] and rel4x4 float64 [B,4,4] ->
+ * counts uint32 [B,2] = {points _point_cloud keeps (x, y, z all non-zero), of those the points
+ * whose projection into the other frame has 0 <= u <= dim_u and 0 <= v <= dim_v}; the
+ * reference's overlap is counts[1] / counts[0].  Bit-identical to slamhip_backproject +
+ * slamhip_reproject (counts) without the point cloud in between: 2 bytes read per pixel.
+ * counts is cleared on the stream.  At most 65535 pairs per call. */
+int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                          double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* stream);
+
 /* ---- device: fused frame-pair kernel (the benchmarked path) --------------- */
 
 /* Bytes of workspace slamhip_pair_loss_fused needs for a batch of B anchors with

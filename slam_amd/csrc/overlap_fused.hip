@@ -1,0 +1,230 @@
+// Overlap of a frame pair straight from the anchor's depth plane, for gfx950 (MI355X): the chain
+// _point_cloud -> _transform_pointcloud -> _backtransform_pointcloud -> _overlap of the reference's frame
+// dropping (slam/preprocess/test_import.py:148-176, called at :204-214) in one pass that reads 2 bytes per
+// pixel and writes two counters per pair, nothing materialised.
+//
+// Arithmetic contract: the two counts (points kept by _point_cloud, and of those the ones whose projection
+// lies in [0, dim_u] x [0, dim_v]) equal what the reference's float64 operation order gives, bit for bit.
+// As in the fused pair-loss kernel (pair_loss.hip) a cheap float64 evaluation of the projection decides
+// every pixel whose coordinates are farther from the window's four borders than a rigorous bound on the
+// distance between the cheap and the reference value; the few pixels within the bound of a border, behind
+// the camera or non-finite are redone in the reference's exact order (geom_device.h).  Only the four
+// borders matter here (no tap choice), so all but a few pixels in 10^6 are decided by the cheap form.
+//
+// HBM-streaming by its bytes, bound by float64 vector instructions (some 21 issue slots per pixel);
+// nothing GEMM-shaped, no MFMA.  Built with -ffp-contract=off like the other geometry files.
+#include "geom_device.h"
+
+namespace slamhip {
+
+constexpr int OVL_TILE_W = 128;   // two waves side by side, a lane is an image column
+#ifndef SLAMHIP_OVL_RPW
+#define SLAMHIP_OVL_RPW 16
+#endif
+constexpr int OVL_RPW = SLAMHIP_OVL_RPW;   // rows a lane walks; the tile's two wave rows give twice as many
+
+struct OvlArgs {
+  Cam cam;
+  // host-rounded quotients of the cheap projection (any rounding is covered by the bound)
+  double fx_fy, fy_fx, inv_fac, inv_fx_fac, inv_fy_fac;
+  double half_u, half_v;   // dim_u / 2, dim_v / 2
+  float axm, aym;          // max |col - cx| / fx and max |row - cy| / fy over the image
+  float extent;            // bound of |u - cx|, |v - cy| for pixels near the window
+  int B, H, W;
+  int cert_ok;             // the constants are mid-range: the cheap form may decide pixels
+  int cx_col, cy_row;      // the column / row with col - cx == 0 / row - cy == 0, or -1
+};
+
+// Constants of the cheap projection that depend on the pair alone (wave-uniform).
+struct OvlConsts {
+  double kAc, kAr, kA0, kBc, kBr, kB0, kCc, kCr, kC0, t0p, t1p, t2, dz;
+  double cu, cv;                       // cx - dim_u / 2, cy - dim_v / 2: the projection comes out centred on the window
+  double in_u, out_u, in_v, out_v;     // |centred coordinate| below in_*: inside for certain; above out_*: outside for certain
+  int cert;
+};
+
+__global__ void __launch_bounds__(256) clear_u32_kernel(unsigned int* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
+__global__ void __launch_bounds__(256)
+overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const double* __restrict__ rel,
+                     unsigned int* __restrict__ counts) {
+  constexpr int RPW = OVL_RPW;
+  __shared__ OvlConsts s_c;
+  __shared__ unsigned int s_cnt[4][2];
+
+  const int H = a.H, W = a.W;
+  const int b = blockIdx.z;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = blockIdx.x * OVL_TILE_W + (wave & 1) * 64 + lane;
+  const int row0 = blockIdx.y * (2 * RPW) + (wave >> 1) * RPW;
+  const int colc = min(col, W - 1);
+  const Pose p = load_pose(rel + 16 * (long long)b);
+
+  // this lane's pixels: raw depth, read once; nothing waits for the loads until the first row
+  const uint16_t* d1b = depth + (long long)b * H * W;
+  unsigned int a_d[RPW];
+#pragma unroll
+  for (int r = 0; r < RPW; ++r) {
+    const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;   // (an image has at most 2^29 pixels)
+    a_d[r] = d1b[(size_t)rw + (unsigned int)colc];
+  }
+
+  // rows of this wave inside the image, and of those the rows with row - cy != 0
+  const int n_in = min(max(H - row0, 0), RPW);
+  const unsigned int rows_in = (1u << n_in) - 1u;     // RPW < 32
+  const unsigned int rz = (unsigned int)(a.cy_row - row0);
+  const unsigned int rows_nz = rows_in & ~((rz < (unsigned int)RPW) ? (1u << rz) : 0u);
+  const unsigned long long col_in = __builtin_amdgcn_ballot_w64(col < W);
+  const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
+
+  // ---- certificate and constants (wave 0, while the others' loads are in flight) ----
+  // With S = 65535/factor * (axm |r0j| + aym |r1j| + |r2j|) + |tj| (the largest sum of magnitudes in the
+  // transform of coordinate j), the reference's x', y', z' and the cheap ones each differ from the real-number
+  // value by at most 8 resp. 24 roundings of 2^-53 S.  For z' above delta_z = 2^-16 Sz the projected coordinate
+  // therefore moves by at most 2^-31 (fx Sx / Sz + |u - cx|), which is below
+  //   eps = 2^-30 ((fx Sx + fy Sy) / Sz + extent)
+  // for every pixel within twice `extent` of the principal point; farther out the error (2^-31 |u - cx| more) is
+  // a vanishing fraction of the distance to the window, which lies within `extent`.  eps_w = max(2 eps, 2^-20)
+  // is the margin kept from the window's borders on either side.
+  if (wave == 0) {
+    const Cam cam = a.cam;
+    OvlConsts c;
+    const float zmaxf = 65535.0f * (float)a.inv_fac;
+    const float Sx = zmaxf * (a.axm * fabsf((float)p.r00) + a.aym * fabsf((float)p.r10) + fabsf((float)p.r20)) + fabsf((float)p.t0);
+    const float Sy = zmaxf * (a.axm * fabsf((float)p.r01) + a.aym * fabsf((float)p.r11) + fabsf((float)p.r21)) + fabsf((float)p.t1);
+    const float Sz = zmaxf * (a.axm * fabsf((float)p.r02) + a.aym * fabsf((float)p.r12) + fabsf((float)p.r22)) + fabsf((float)p.t2);
+    const float delta_z = Sz * 0x1p-16f;
+    const float ratio = ((float)cam.fx * Sx + (float)cam.fy * Sy) / Sz;
+    const float eps = 0x1p-30f * (ratio + a.extent);
+    const float eps_w = fmaxf(2.0f * eps, 0x1p-20f);
+    c.in_u = a.half_u - (double)eps_w; c.out_u = a.half_u + (double)eps_w;
+    c.in_v = a.half_v - (double)eps_w; c.out_v = a.half_v + (double)eps_w;
+    c.cert = (a.cert_ok != 0) && (eps_w <= 0x1p-7f) && (delta_z > 0.0f) && (delta_z < 3.0e38f) &&
+             (c.in_u > 0.0) && (c.in_v > 0.0);   // NaN fails
+    c.dz = (double)delta_z;
+    // u - dim_u/2 = (z A + t0') / (z C + t2) + (cx - dim_u/2) with
+    //   A = (col-cx) r00 + (row-cy) (fx/fy) r10 + fx r20,  C = ((col-cx)/fx) r02 + ((row-cy)/fy) r12 + r22
+    // (all divided by factor: z is the raw depth), likewise v; A, B, C advance by a constant per row
+    c.kAc = p.r00 * a.inv_fac; c.kAr = (a.fx_fy * p.r10) * a.inv_fac; c.kA0 = (cam.fx * p.r20) * a.inv_fac;
+    c.kBc = (a.fy_fx * p.r01) * a.inv_fac; c.kBr = p.r11 * a.inv_fac; c.kB0 = (cam.fy * p.r21) * a.inv_fac;
+    c.kCc = p.r02 * a.inv_fx_fac; c.kCr = p.r12 * a.inv_fy_fac; c.kC0 = p.r22 * a.inv_fac;
+    c.t0p = cam.fx * p.t0; c.t1p = cam.fy * p.t1; c.t2 = p.t2;
+    c.cu = cam.cx - a.half_u; c.cv = cam.cy - a.half_v;
+    if (lane == 0) s_c = c;
+  }
+  __syncthreads();
+  const OvlConsts pc = s_c;
+  const bool cert_u = __builtin_amdgcn_readfirstlane(pc.cert) != 0;
+
+  unsigned int n_valid0 = 0u, n_inb = 0u;   // wave-uniform counts of the decided pixels
+  unsigned int rest_bits = 0u;              // bit r: row r of this lane is left to the exact form
+
+  if (cert_u) {
+    const double ucx = (double)col - a.cam.cx, vcy0 = (double)row0 - a.cam.cy;
+    double A = fma(ucx, pc.kAc, fma(vcy0, pc.kAr, pc.kA0));
+    double Bq = fma(ucx, pc.kBc, fma(vcy0, pc.kBr, pc.kB0));
+    double C = fma(ucx, pc.kCc, fma(vcy0, pc.kCr, pc.kC0));
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const unsigned int draw = a_d[r];
+      const double z = (double)draw;
+      const double X = fma(z, A, pc.t0p), Y = fma(z, Bq, pc.t1p), Z = fma(z, C, pc.t2);
+      A += pc.kAr; Bq += pc.kBr; C += pc.kCr;
+      double rcp = __builtin_amdgcn_rcp(Z);
+      rcp = fma(rcp, fma(-Z, rcp, 1.0), rcp);
+      const double du = fabs(fma(X, rcp, pc.cu)), dv = fabs(fma(Y, rcp, pc.cv));   // distance from the window's centre
+      unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
+      if (!((rows_nz >> r) & 1u)) m_valid0 = 0ull;
+      const unsigned long long m_z = m_valid0 & __builtin_amdgcn_ballot_w64(Z > pc.dz);
+      const unsigned long long m_in = m_z & __builtin_amdgcn_ballot_w64(du < pc.in_u) & __builtin_amdgcn_ballot_w64(dv < pc.in_v);
+      const unsigned long long m_out = m_z & (__builtin_amdgcn_ballot_w64(du > pc.out_u) | __builtin_amdgcn_ballot_w64(dv > pc.out_v));
+      n_valid0 += (unsigned int)__popcll(m_in | m_out);
+      n_inb += (unsigned int)__popcll(m_in);
+      const unsigned long long m_rest = m_valid0 & ~(m_in | m_out);   // near a border, behind the camera, non-finite
+      if (m_rest != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
+    }
+  } else {
+    // no certificate (constants out of range, a degenerate pose): every pixel in the image
+    rest_bits = __builtin_amdgcn_inverse_ballot_w64(col_in) ? rows_in : 0u;
+  }
+
+  // ---- the reference's exact operation order for the pixels left ----
+  if (__builtin_amdgcn_ballot_w64(rest_bits != 0u) != 0ull) {
+    const double dim_u = 2.0 * a.half_u, dim_v = 2.0 * a.half_v;   // (exact: the halves are the host's dim / 2)
+#pragma unroll 1
+    for (int r = 0; r < RPW; ++r) {
+      const bool need = (rest_bits >> r) & 1u;
+      if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+      bool valid0 = false, inb = false;
+      if (need) {
+        const int row = row0 + r;
+        const unsigned int draw = d1b[(long long)row * W + col];
+        double x, y, z, x2, y2, z2, u, v;
+        backproject_px(a.cam, col, row, draw, x, y, z);
+        valid0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
+        transform_px(p, x, y, z, x2, y2, z2);
+        project_px(a.cam, x2, y2, z2, u, v);
+        inb = valid0 && in_window(u, v, dim_u, dim_v);
+      }
+      n_valid0 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(valid0));
+      n_inb += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(inb));
+    }
+  }
+
+  // ---- the four waves through LDS, one atomic instruction per workgroup ----
+  if (lane == 0) { s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; }
+  __syncthreads();
+  if (tid < 2) {
+    const unsigned int c = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
+    if (c) atomicAdd(&counts[2 * (long long)b + tid], c);
+  }
+}
+
+}  // namespace slamhip
+
+using namespace slamhip;
+
+extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                                     double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* stream) {
+  SLAMHIP_REQUIRE(B >= 0 && H > 0 && W > 0, SLAMHIP_E_ARG, "overlap_fused: bad shape B=%d H=%d W=%d", B, H, W);
+  if (B == 0) return SLAMHIP_OK;
+  SLAMHIP_REQUIRE(depth && rel4x4 && K && counts, SLAMHIP_E_ARG, "overlap_fused: null pointer");
+  SLAMHIP_REQUIRE(H <= 32767 && W <= 65535 && (long long)H * W <= 0x20000000LL, SLAMHIP_E_SIZE,
+                  "overlap_fused: image larger than 65535 x 32767 or 2^29 pixels");
+  SLAMHIP_REQUIRE((reinterpret_cast<uintptr_t>(depth) % 2) == 0 && (reinterpret_cast<uintptr_t>(rel4x4) % 8) == 0 &&
+                      (reinterpret_cast<uintptr_t>(counts) % 4) == 0,
+                  SLAMHIP_E_ARG, "overlap_fused: misaligned input or output");
+  const int tiles_x = (W + OVL_TILE_W - 1) / OVL_TILE_W, tiles_y = (H + 2 * OVL_RPW - 1) / (2 * OVL_RPW);
+  SLAMHIP_REQUIRE(B <= 65535 && tiles_y <= 65535, SLAMHIP_E_SIZE, "overlap_fused: more than 65535 pairs per call");
+  hipStream_t s = (hipStream_t)stream;
+  OvlArgs a;
+  a.cam = Cam{K[0], K[1], K[2], K[3], factor};
+  a.B = B; a.H = H; a.W = W;
+  // the cheap form assumes that no intermediate comes near the denormal or overflow range ("x, y, z all non-zero"
+  // is then "raw depth, col - cx and row - cy all non-zero"): constants in [2^-64, 2^64], principal point in
+  // [2^-32, 2^32], a finite window; its error bound covers the roundings of the quotients below
+  auto mid = [](double v) { const double m = fabs(v); return m >= 0x1p-64 && m <= 0x1p64; };
+  auto pp = [](double v) { const double m = fabs(v); return m >= 0x1p-32 && m <= 0x1p32; };
+  a.cert_ok = mid(K[0]) && mid(K[1]) && mid(factor) && pp(K[2]) && pp(K[3]) && dim_u > 0.0 && dim_v > 0.0 &&
+              dim_u <= 0x1p24 && dim_v <= 0x1p24;
+  a.fx_fy = K[0] / K[1]; a.fy_fx = K[1] / K[0];
+  a.inv_fac = 1.0 / factor; a.inv_fx_fac = 1.0 / (K[0] * factor); a.inv_fy_fac = 1.0 / (K[1] * factor);
+  a.half_u = 0.5 * dim_u; a.half_v = 0.5 * dim_v;
+  a.axm = (float)(fmax(fabs(K[2]), fabs((double)(W - 1) - K[2])) / fabs(K[0]) * 1.0001);
+  a.aym = (float)(fmax(fabs(K[3]), fabs((double)(H - 1) - K[3])) / fabs(K[1]) * 1.0001);
+  // bound of |u - cx|, |v - cy| over the window and the image together
+  a.extent = (float)(fmax((double)W, dim_u) + fmax((double)H, dim_v) + fabs(K[2]) + fabs(K[3]) + 8.0);
+  auto int_index = [](double c, int n) { return (c >= 0.0 && c < (double)n && c == floor(c)) ? (int)c : -1; };
+  a.cx_col = int_index(K[2], W);
+  a.cy_row = int_index(K[3], H);
+  // the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds kernel nodes only)
+  hipLaunchKernelGGL(clear_u32_kernel, dim3((unsigned)((2LL * B + 255) / 256)), dim3(256), 0, s, counts, 2LL * B);
+  hipLaunchKernelGGL(overlap_fused_kernel, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)B), dim3(256), 0, s, a,
+                     depth, rel4x4, counts);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}

@@ -101,6 +101,25 @@ def overlap_count(uvd, dim, want_mask=False):
     return cnt, mask
 
 
+def overlap_fused(depth, rel, K, dim, factor=FACTOR):
+    """depth uint16 [B,H,W], rel float64 [B,4,4] -> counts int32 [B,2] = {points the reference's _point_cloud
+    keeps, of those the ones projected into [0, dim[0]] x [0, dim[1]]} (test_import.py:148-176 in one pass over
+    the depth plane; the overlap of :176 is counts[:,1] / counts[:,0])."""
+    d = _dev(depth, torch.uint16, "depth")
+    if d.dim() != 3:
+        raise ValueError("depth must be [B,H,W]")
+    B, H, W = d.shape
+    r = _dev(rel, torch.float64, "rel")
+    if tuple(r.shape) != (B, 4, 4):
+        raise ValueError("rel must be [B,4,4]")
+    counts = torch.empty((B, 2), dtype=torch.int32, device=d.device)
+    lib = capi.load()
+    capi.check(lib.slamhip_overlap_fused(d.data_ptr(), r.data_ptr(), capi.K4(K), float(factor), float(dim[0]),
+                                         float(dim[1]), B, H, W, counts.data_ptr(), capi.current_stream()),
+               "slamhip_overlap_fused")
+    return counts
+
+
 def _pair_args(depth1, rgb1, depth2, rgb2, rel):
     d1 = _dev(depth1, torch.uint16, "depth1")
     c1 = _dev(rgb1, torch.uint8, "rgb1")

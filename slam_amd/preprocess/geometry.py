@@ -90,7 +90,8 @@ def _overlap(backtransform, dim):
 def _get_data(associations, groundtruth, sequence_length, dynamic_drop=0.0, static_drop=1,
               read_depth=None, rng=np.random, clamp=False):
     """test_import.py:178-246.  Labels on the host C path, the overlap test of the
-    dynamic drop on the GPU with the previous frame's cloud kept resident.
+    dynamic drop on the GPU in one pass over the previous frame's depth plane, which stays
+    resident (slamhip_overlap_fused: the counts of :148-176 without the point cloud).
     `read_depth(path) -> uint16 [H,W]` replaces the reference's PNG read (:204).
     clamp=True takes the twist with the clamped arccos argument, the variant the
     queued provider's copy of this function calls (model_input.py:46-54, 243-319)."""
@@ -105,19 +106,16 @@ def _get_data(associations, groundtruth, sequence_length, dynamic_drop=0.0, stat
     gt7 = np.stack([groundtruth[:, 1:][_find_label(groundtruth[:, 0], associations[i, 0])].astype(np.float32)
                     for i in range(n)]) if n else np.zeros((0, 7), np.float32)
     old = 0  # index of the last kept frame
-    cloud_old = None
+    depth_old = None
     overlap = None
     for i in range(n):
         if drop:
             d = torch.from_numpy(np.ascontiguousarray(read_depth(associations[i, 3]), dtype=np.uint16)[None]).to(_device())
-            cloud = fp.backproject(d, K, FACTOR, torch.float64)
         if i > 0:
             rel, tw = fp.pose_batch(gt7[old:old + 1], gt7[i:i + 1], clamp)
             if drop:
-                xyz, valid0 = cloud_old
-                out = fp.reproject(xyz, torch.from_numpy(rel).to(xyz.device), K, (640, 480), valid0=valid0,
-                                   want=("counts",))
-                c = out["counts"].cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+                c = fp.overlap_fused(depth_old, torch.from_numpy(rel).to(depth_old.device), K, (640.0, 480.0), FACTOR)
+                c = c.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
                 overlap = float(c[0, 1]) / float(c[0, 0])
                 if overlap < dynamic_drop:
                     twist[i] = tw[0]
@@ -128,7 +126,7 @@ def _get_data(associations, groundtruth, sequence_length, dynamic_drop=0.0, stat
         if i == 0 or (drop and overlap < dynamic_drop):
             old = i
         if drop:
-            cloud_old = cloud
+            depth_old = d
     if drop:
         twist = np.delete(twist, delete_list, 0)
         rgb_filepaths = np.delete(rgb_filepaths, delete_list, 0)
