@@ -19,7 +19,7 @@ namespace slamhip {
 
 constexpr int OVL_TILE_W = 128;   // two waves side by side, a lane is an image column
 #ifndef SLAMHIP_OVL_RPW
-#define SLAMHIP_OVL_RPW 16
+#define SLAMHIP_OVL_RPW 24
 #endif
 constexpr int OVL_RPW = SLAMHIP_OVL_RPW;   // rows a lane walks; the tile's two wave rows give twice as many
 
