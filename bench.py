@@ -255,6 +255,53 @@ def main():
     # launch of the whole run stands in (never the default)
     launch_ms = ev0.elapsed_time(ev1) / max(1, a.steps) if not side else elapsed / max(1, a.steps) * 1e3
 
+    # Secondary measurement (never part of `value`): the reference's own subset of the path, the overlap of
+    # test_import.py:148-176 (depth plane in, two counters out: 2 algorithmic bytes per pixel), on the anchors'
+    # depth planes of the same HBM batches; its counts must equal the fused kernel's first two counters.
+    overlap = None
+    if rank == 0 and k == 1:
+        try:
+            from slam_amd import capi
+            lib = capi.load()
+            oc = torch.empty((B, 2), dtype=torch.int32, device=dev)
+            K4, stream = capi.K4(K), capi.current_stream()
+
+            # depth planes alone are a fifth of a batch: copies, so that the planes walked exceed the 256 MB Infinity Cache
+            n_copies = max(len(bufs), -(-320 * 2 ** 20 // (B * H * W * 2)))
+            planes = [(bufs[i % len(bufs)][0] if i < len(bufs) else bufs[i % len(bufs)][0].clone(), bufs[i % len(bufs)][4])
+                      for i in range(n_copies)]
+
+            def ovl(i):
+                dpl, rl = planes[i % n_copies]
+                capi.check(lib.slamhip_overlap_fused(dpl.data_ptr(), rl.data_ptr(), K4, float(a.factor), float(W), float(H),
+                                                     B, H, W, oc.data_ptr(), stream), "slamhip_overlap_fused")
+            n_ovl = 400
+            for i in range(100):
+                ovl(i)
+            torch.cuda.synchronize()
+            o0, o1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            o0.record()
+            for i in range(n_ovl):
+                ovl(i)
+            o1.record()
+            torch.cuda.synchronize()
+            call_ms = o0.elapsed_time(o1) / n_ovl
+            last_i = ((n_ovl - 1) % n_copies) % len(bufs)
+            same = bool(torch.equal(oc, plans[last_i].run()[1].reshape(B, -1)[:, :2].to(torch.int32)))
+            ovl_bytes = B * H * W * 2
+            overlap = {"workload": "slamhip_overlap_fused on the %d anchor depth planes of a batch (counts of _point_cloud -> "
+                                   "_transform_pointcloud -> _backtransform_pointcloud -> _overlap, no intermediates)" % B,
+                       "pairs_per_s": B / (call_ms * 1e-3), "call_ms": call_ms, "calls": n_ovl, "depth_batches_rotated": n_copies,
+                       "roofline": {"bound": "hbm", "achieved": ovl_bytes / (call_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                                    "unit": "GB/s", "frac": ovl_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "algorithmic_bytes_per_call": ovl_bytes,
+                                    "note": "a call is a counter-clearing kernel plus overlap_fused_kernel"},
+                       "counts_equal_fused_kernel": same}
+            if not same:
+                overlap["error"] = "counts differ from the fused kernel's"
+        except Exception as e:
+            overlap = {"error": "%s: %s" % (type(e).__name__, e)}
+
     # Secondary measurement (never part of `value`): the encoder's training step, batch 128 on
     # one GPU, 64 per GPU data-parallel with the RCCL gradient all-reduce on several.
     encoder = None
@@ -363,6 +410,7 @@ def main():
             "cpu_baseline": cb,
             "cpu_baseline_all_cores": cb_all,
             "verified_against_oracle": verified,
+            "overlap_subset": overlap,
             "encoder": encoder,
             "train_step": train,
         }
@@ -370,8 +418,9 @@ def main():
         if verified is False:
             print("bench: the last step's results do not match the oracle", file=sys.stderr)
             status = 1
-        if (encoder or {}).get("error") or (train or {}).get("error"):
-            print("bench: a secondary measurement failed: %s" % ((encoder or {}).get("error") or train.get("error")), file=sys.stderr)
+        if (encoder or {}).get("error") or (train or {}).get("error") or (overlap or {}).get("error"):
+            print("bench: a secondary measurement failed: %s"
+                  % ((encoder or {}).get("error") or (train or {}).get("error") or overlap.get("error")), file=sys.stderr)
             status = 1
     if dist is not None:
         dist.destroy_process_group()

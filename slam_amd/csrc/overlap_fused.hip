@@ -11,8 +11,17 @@
 // the camera or non-finite are redone in the reference's exact order (geom_device.h).  Only the four
 // borders matter here (no tap choice), so all but a few pixels in 10^6 are decided by the cheap form.
 //
-// HBM-streaming by its bytes, bound by float64 vector instructions (some 21 issue slots per pixel);
-// nothing GEMM-shaped, no MFMA.  Built with -ffp-contract=off like the other geometry files.
+// Most pixels are not projected at all.  For a fixed depth the projection is a projective map of the pixel
+// coordinates with a positive denominator (z' > 0), which takes a wave's 64 x RPW rectangle to a convex
+// quadrilateral, and as the depth of one pixel varies its projection moves along a segment; so every pixel of
+// the rectangle with a depth in [z_min, z_max] projects into the convex hull of the rectangle's four corners
+// taken at z_min and at z_max.  When these eight points lie inside the window by the certificate's margin
+// (or all beyond one of its borders by that margin), so does every pixel, in the reference's arithmetic too,
+// and the wave only counts its non-zero depths: 4 instead of 21 vector instructions per pixel.  Waves whose
+// rectangle straddles a border project pixel by pixel.
+//
+// HBM-streaming by its bytes, bound by vector instructions; nothing GEMM-shaped, no MFMA.  Built with
+// -ffp-contract=off like the other geometry files.
 #include "geom_device.h"
 
 namespace slamhip {
@@ -43,6 +52,30 @@ struct OvlConsts {
   int cert;
 };
 
+// unsigned min / max over the wave by DPP steps, valid in lane 63 (masked-out rows receive the identity)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int ovl_dpp(unsigned int old, unsigned int v) {
+  return (unsigned int)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ unsigned int wave_umin63(unsigned int v) {
+  v = min(v, ovl_dpp<0xB1, 0xF>(0xffffffffu, v));    // quad_perm [1,0,3,2]
+  v = min(v, ovl_dpp<0x4E, 0xF>(0xffffffffu, v));    // quad_perm [2,3,0,1]
+  v = min(v, ovl_dpp<0x141, 0xF>(0xffffffffu, v));   // row_half_mirror
+  v = min(v, ovl_dpp<0x140, 0xF>(0xffffffffu, v));   // row_mirror
+  v = min(v, ovl_dpp<0x142, 0xA>(0xffffffffu, v));   // row_bcast15 into rows 1, 3
+  v = min(v, ovl_dpp<0x143, 0xC>(0xffffffffu, v));   // row_bcast31 into rows 2, 3
+  return v;
+}
+__device__ __forceinline__ unsigned int wave_umax63(unsigned int v) {
+  v = max(v, ovl_dpp<0xB1, 0xF>(0u, v));
+  v = max(v, ovl_dpp<0x4E, 0xF>(0u, v));
+  v = max(v, ovl_dpp<0x141, 0xF>(0u, v));
+  v = max(v, ovl_dpp<0x140, 0xF>(0u, v));
+  v = max(v, ovl_dpp<0x142, 0xA>(0u, v));
+  v = max(v, ovl_dpp<0x143, 0xC>(0u, v));
+  return v;
+}
+
 __global__ void __launch_bounds__(256) clear_u32_kernel(unsigned int* __restrict__ p, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -71,6 +104,16 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   for (int r = 0; r < RPW; ++r) {
     const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;   // (an image has at most 2^29 pixels)
     a_d[r] = d1b[(size_t)rw + (unsigned int)colc];
+  }
+
+  // pixels outside the image count as depth 0 (only the tiles of the right and bottom edge have any)
+  if (col >= W) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) a_d[r] = 0u;
+  }
+  if (row0 + RPW > H) {
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) a_d[r] = (row0 + r < H) ? a_d[r] : 0u;
   }
 
   // rows of this wave inside the image, and of those the rows with row - cy != 0
@@ -123,7 +166,51 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   unsigned int n_valid0 = 0u, n_inb = 0u;   // wave-uniform counts of the decided pixels
   unsigned int rest_bits = 0u;              // bit r: row r of this lane is left to the exact form
 
+  // ---- the wave's rectangle as a whole: depth range, number of kept points, the eight hull points ----
+  bool whole = false;
   if (cert_u) {
+    unsigned int zmn = 0xffffffffu, zmx = 0u, n_kept = 0u;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const unsigned int draw = a_d[r];
+      zmn = min(zmn, draw - 1u);   // (depth 0 wraps to the identity of the minimum)
+      zmx = max(zmx, draw);
+      const unsigned long long m = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
+      n_kept += ((rows_nz >> r) & 1u) ? (unsigned int)__popcll(m) : 0u;
+    }
+    const unsigned int z_lo = (unsigned int)__builtin_amdgcn_readlane((int)wave_umin63(zmn), 63) + 1u;
+    const unsigned int z_hi = (unsigned int)__builtin_amdgcn_readlane((int)wave_umax63(zmx), 63);
+    if (z_hi == 0u) {
+      whole = true;   // no depth at all: nothing kept
+    } else {
+      // lane l < 8: corner (l & 1 ? last : first column, l & 2 ? last : first row) at (l & 4 ? z_hi : z_lo)
+      const int wc0 = blockIdx.x * OVL_TILE_W + (wave & 1) * 64;
+      const double ccol = (double)((lane & 1) ? min(wc0 + 63, W - 1) : wc0) - a.cam.cx;
+      const double crow = (double)((lane & 2) ? min(row0 + RPW - 1, H - 1) : row0) - a.cam.cy;
+      const double z = (double)((lane & 4) ? z_hi : z_lo);
+      const double Ac = fma(ccol, pc.kAc, fma(crow, pc.kAr, pc.kA0));
+      const double Bc = fma(ccol, pc.kBc, fma(crow, pc.kBr, pc.kB0));
+      const double Cc = fma(ccol, pc.kCc, fma(crow, pc.kCr, pc.kC0));
+      const double X = fma(z, Ac, pc.t0p), Y = fma(z, Bc, pc.t1p), Z = fma(z, Cc, pc.t2);
+      double rcp = __builtin_amdgcn_rcp(Z);
+      rcp = fma(rcp, fma(-Z, rcp, 1.0), rcp);
+      const double su = fma(X, rcp, pc.cu), sv = fma(Y, rcp, pc.cv);   // centred on the window
+      auto all8 = [&](bool c) { return (__builtin_amdgcn_ballot_w64(c) & 0xffull) == 0xffull; };   // NaN fails
+      if (all8(Z > pc.dz)) {
+        if (all8(fabs(su) < pc.in_u) && all8(fabs(sv) < pc.in_v)) {
+          whole = true;
+          n_valid0 = n_kept; n_inb = n_kept;
+        } else if (all8(su < -pc.out_u) || all8(su > pc.out_u) || all8(sv < -pc.out_v) || all8(sv > pc.out_v)) {
+          whole = true;
+          n_valid0 = n_kept;
+        }
+      }
+    }
+  }
+
+  if (whole) {
+    // decided above
+  } else if (cert_u) {
     const double ucx = (double)col - a.cam.cx, vcy0 = (double)row0 - a.cam.cy;
     double A = fma(ucx, pc.kAc, fma(vcy0, pc.kAr, pc.kA0));
     double Bq = fma(ucx, pc.kBc, fma(vcy0, pc.kBr, pc.kB0));

@@ -129,6 +129,47 @@ def test_bench_size_against_the_materialising_kernels(fp):
         assert tuple(got[b]) == _oracle_counts(depth[b], rel[b], K, (640.0, 480.0), 1.0)
 
 
+def test_large_motions_whole_rectangles_inside_outside_and_straddling(fp):
+    """Poses that leave whole 64 x 24 rectangles inside the window, whole ones beyond each of its four borders
+    and many across them (rotations about the optical axis, sideways and vertical translations, a pitch that
+    brings z' near zero for part of the frame), on per-pixel random metric depth (parallax of tens of pixels
+    inside one rectangle) and on plane depth: counts of the materialising kernels bit for bit, three pairs
+    against the reference chain."""
+    H, W = 480, 640
+    K = fp.intrinsics(1)
+
+    def rot(axis, deg):
+        c, s_ = np.cos(np.deg2rad(deg)), np.sin(np.deg2rad(deg))
+        R = np.eye(4)
+        i, j = [(1, 2), (0, 2), (0, 1)][axis]
+        R[i, i] = c; R[i, j] = -s_; R[j, i] = s_; R[j, j] = c
+        return R
+
+    def trans(x, y, z):
+        T = np.eye(4)
+        T[:3, 3] = [x, y, z]
+        return T
+
+    rels = [rot(2, 30.0), rot(2, -75.0), trans(1.2, 0.0, 0.0), trans(-0.9, 0.0, 0.0), trans(0.0, 0.8, 0.0),
+            trans(0.0, -1.1, 0.0), trans(0.0, 0.0, -0.45), trans(0.0, 0.0, 2.0), rot(0, 40.0), rot(1, -35.0) @ trans(0.3, 0.1, 0.2),
+            rot(2, 180.0), trans(5.0, 0.0, 0.0)]
+    rel = np.stack(rels)
+    B = rel.shape[0]
+    for kind in ("noise", "plane"):
+        depth = syn.depth_frames(B, H, W, seed=11, kind=kind)
+        depth[1, 100:200, :] = 0
+        depth[2, :, 300:310] = 0
+        d = _dev(depth)
+        got = _u32(fp.overlap_fused(d, _dev(rel), K, (640.0, 480.0), 5000.0))
+        xyz, valid0 = fp.backproject(d, K, 5000.0, torch.float64)
+        want = _u32(fp.reproject(xyz, _dev(rel), K, (640, 480), valid0=valid0, want=("counts",))["counts"])
+        assert np.array_equal(got, want), (kind, got.tolist(), want.tolist())
+        frac = got[:, 1] / np.maximum(got[:, 0], 1)
+        assert frac.min() < 0.05 and frac.max() > 0.5 and ((frac > 0.1) & (frac < 0.9)).sum() >= 3, frac.tolist()
+        for b in (0, 2, 9):
+            assert tuple(got[b]) == _oracle_counts(depth[b], rel[b], K, (640.0, 480.0), 5000.0)
+
+
 def test_argument_errors(fp):
     from slam_amd import capi
     lib = capi.load()
