@@ -923,8 +923,8 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   SLAMHIP_REQUIRE(aligned_to(workspace, 8) && aligned_to(sums, 8) && aligned_to(counts, 4) && aligned_to(depth1, 2) &&
                   aligned_to(depth2, 2) && aligned_to(rel4x4, 8), SLAMHIP_E_ARG,
                   "%s: misaligned workspace, input or output", who);
-  // One workgroup per tile of one (anchor, neighbour) pair, 128 x 24 pixels on four waves: that kernel is
-  // straight-line code (no loop over neighbours), needs 99 vector registers and 39 KB of LDS, and four
+  // One workgroup per tile of one (anchor, neighbour) pair, 128 x 24 or 128 x 16 pixels on four waves: that kernel is
+  // straight-line code (no loop over neighbours), needs 99 / 86 vector registers and 39 / 30 KB of LDS, and four / five
   // workgroups share a compute unit.  The form that walks an anchor's k neighbours in one workgroup and reads the
   // anchor tile once (168 registers, 128 x 32 tiles, three workgroups per compute unit) is slower although it
   // reads less - the kernel is bound by vector instructions, and the k pairs of an anchor tile run back to
@@ -936,7 +936,8 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   static const int tile_env = []() {
     const char* e = getenv("SLAMHIP_TILE");
     const std::string v = e ? e : "";
-    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : v == "32x16" ? 5 : 0;
+    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : v == "32x16" ? 5 : v == "12x6" ? 6 :
+           v == "20x10" ? 7 : v == "8x4" ? 8 : 0;
   }();
   static const bool shared_env = []() { const char* e = getenv("SLAMHIP_SHARED_ANCHORS"); return e && atoi(e) != 0; }();
   const bool shared_anchors = shared_env && k > 1;
@@ -944,10 +945,15 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   constexpr int tile_env = 0;
   constexpr bool shared_anchors = false;
 #endif
-  // (128 x 16 tiles, five workgroups per compute unit, are 3-4 % ahead of 128 x 24 when neighbours share anchors
-  // through L2, and 3 % behind for k = 1)
-  const int tile_cfg = tile_env ? tile_env : (shared_anchors ? 5 : k == 1 ? 3 : 2);
-  const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : 32;
+  // 128 x 16 tiles (five workgroups per compute unit) are 3-4 % ahead of 128 x 24 when neighbours share anchors
+  // through L2.  For k = 1 the launch size decides: the smaller tile's workgroups live shorter, so the launch
+  // fills and drains faster, the larger tile spends fewer instructions per pixel; measured at 640 x 480 per
+  // launch of 16 / 32 / 64 / 96 / 128 / 256 pairs, 128 x 16 against 128 x 24: 20.0 / 21.3, 35.8 / 36.9, 64.1 / 65.2,
+  // 94.8 / 93.5, 125.3 / 121.5, 246.2 / 238.9 us.  The crossover is near eight rounds of the chip's 1024 workgroup slots.
+  const long long wgs24 = (long long)B * ((W + TILE_W - 1) / TILE_W) * ((H + 23) / 24);
+  const int tile_cfg = tile_env ? tile_env : (shared_anchors ? 5 : (k == 1 && wgs24 > 8 * 1024) ? 3 : 2);
+  const int tile_h = tile_cfg == 1 || tile_cfg == 2 ? 16 : tile_cfg == 3 ? 24 : tile_cfg == 6 ? 12 : tile_cfg == 7 ? 20 :
+                     tile_cfg == 8 ? 8 : 32;
   FusedArgs a;
   PairAcc* ws = (PairAcc*)workspace;
   a.cam = Cam{K[0], K[1], K[2], K[3], factor};
@@ -1003,6 +1009,9 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
       case 2: SLAMHIP_LAUNCH_FUSED(16, 8, true); break;
       case 4: SLAMHIP_LAUNCH_FUSED(32, 32, true); break;
       case 5: SLAMHIP_LAUNCH_FUSED(32, 16, true); break;
+      case 6: SLAMHIP_LAUNCH_FUSED(12, 6, true); break;
+      case 7: SLAMHIP_LAUNCH_FUSED(20, 10, true); break;
+      case 8: SLAMHIP_LAUNCH_FUSED(8, 4, true); break;
       default: SLAMHIP_LAUNCH_FUSED(24, 12, true); break;
     }
   }

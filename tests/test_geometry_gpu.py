@@ -292,6 +292,28 @@ def test_fused_equals_materialised_at_bench_size(fp):
     assert (cnt[:, 2] > 0.5 * 480 * 640).all()  # TUM-like motion keeps most pixels in view
 
 
+def test_both_tile_shapes_of_the_single_neighbour_kernel(fp):
+    """Single-neighbour launches take 128 x 16 tiles up to eight rounds of workgroups and 128 x 24 tiles beyond:
+    960 pairs of 72 x 384 in one call (128 x 24) against the same pairs in calls of 240 (128 x 16), counts bit for
+    bit, and the first and last pairs against the oracle."""
+    B, H, W = 960, 72, 384
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    assert B * 3 * 3 > 8 * 1024 >= 240 * 3 * 5      # workgroups of 128 x 24 tiles in the large and the small calls
+    d1, c1, d2, c2, rel = _pairs(B, 1, H, W, seed=21, depth_kind="noise", rgb_kind="noise")
+    d1[3, ::4, ::3] = 0
+    D = [_dev(x) for x in (d1, c1, d2, c2, rel)]
+    big_s, big_c = fp.pair_loss(*D, K, 1.0)
+    for lo in range(0, B, 240):
+        sl = slice(lo, lo + 240)
+        s, c = fp.pair_loss(*[x[sl].contiguous() for x in D], K, 1.0)
+        assert torch.equal(c, big_c[sl])
+        np.testing.assert_allclose(s.cpu().numpy(), big_s[sl].cpu().numpy(), rtol=2e-6)   # (a wave adds its lanes in float32)
+    for sl in (slice(0, 4), slice(B - 4, B)):
+        want_s, want_c = so.pair_loss(d1[sl], c1[sl], d2[sl], c2[sl], rel[sl], K, 1.0)
+        assert np.array_equal(_u32(big_c[sl]), want_c.astype(np.int64))
+        np.testing.assert_allclose(big_s[sl].cpu().numpy(), want_s, rtol=RTOL, atol=1e-6)
+
+
 def test_high_res_four_neighbours(fp):
     """1280x960 frames, k = 4 neighbours per anchor, intrinsics doubled (the high-resolution
     configuration): counts and sums of the fused kernel against the materialised per-pixel
