@@ -56,6 +56,16 @@ __device__ __forceinline__ bool in_window(double u, double v, double du, double 
   return (0.0 <= u) & (u <= du) & (0.0 <= v) & (v <= dv);   // '&': four compares, no branches
 }
 
+// Counters that kernels add into are cleared by this kernel on the stream, not by hipMemsetAsync: a sequence of
+// calls recorded in a HIP graph then holds kernel nodes only.
+static __global__ void __launch_bounds__(256) clear_u32_kernel(unsigned int* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+static inline void clear_u32_async(unsigned int* p, long long n, hipStream_t s) {
+  hipLaunchKernelGGL(clear_u32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
+}
+
 // floor to int32, saturating, NaN -> INT32_MIN
 __device__ __forceinline__ int32_t pixel_index(double c) {
   if (c != c) return INT_MIN;

@@ -296,7 +296,7 @@ int slamhip_reproject(const void* xyz, int xyz_f64, const uint8_t* valid0, const
   if (B == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE(xyz && K, SLAMHIP_E_ARG, "reproject: null xyz or K");
   hipStream_t s = (hipStream_t)stream;
-  if (counts && B > 0) SLAMHIP_HIP(hipMemsetAsync(counts, 0, sizeof(uint32_t) * 2 * (size_t)B, s));
+  if (counts && B > 0) clear_u32_async(counts, 2LL * B, s);
   if (B == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE((long long)H * W <= 0x7fffff00LL, SLAMHIP_E_SIZE, "reproject: image too large");
   const int HW = H * W;
@@ -320,7 +320,7 @@ int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double d
                           uint32_t* count, void* stream) {
   SLAMHIP_REQUIRE(uvd && count && n >= 0, SLAMHIP_E_ARG, "overlap_count: null pointer or n<0");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(count, 0, sizeof(uint32_t), s));
+  clear_u32_async(count, 1, s);
   if (n == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE((n + 255) / 256 <= 0x7fffffffLL, SLAMHIP_E_SIZE, "overlap_count: too many points");
   hipLaunchKernelGGL(overlap_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, uvd, n, dim_u,

@@ -76,11 +76,6 @@ __device__ __forceinline__ unsigned int wave_umax63(unsigned int v) {
   return v;
 }
 
-__global__ void __launch_bounds__(256) clear_u32_kernel(unsigned int* __restrict__ p, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) p[i] = 0u;
-}
-
 __global__ void __launch_bounds__(256)
 overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const double* __restrict__ rel,
                      unsigned int* __restrict__ counts) {
@@ -309,7 +304,7 @@ extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
   // the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds kernel nodes only)
-  hipLaunchKernelGGL(clear_u32_kernel, dim3((unsigned)((2LL * B + 255) / 256)), dim3(256), 0, s, counts, 2LL * B);
+  clear_u32_async(counts, 2LL * B, s);
   hipLaunchKernelGGL(overlap_fused_kernel, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)B), dim3(256), 0, s, a,
                      depth, rel4x4, counts);
   SLAMHIP_HIP(hipGetLastError());

@@ -16,6 +16,13 @@ namespace slamhip {
 
 typedef __bf16 bf16_t;
 
+// the workspace (sums, per-frame maxima) is cleared by a kernel, not by hipMemsetAsync: calls recorded in a HIP
+// graph then hold kernel nodes only
+__global__ void __launch_bounds__(256) clear_words_kernel(unsigned int* __restrict__ p, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned int pk_max_u16(unsigned int a, unsigned int b) {
   return __builtin_bit_cast(unsigned int, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
@@ -206,7 +213,10 @@ int slamhip_prep_rgbd(const uint8_t* rgb, const uint16_t* depth, int B, int Hs, 
   hipStream_t s = (hipStream_t)stream;
   double* sums = (double*)workspace;                              // two sets of 4 doubles (64 bytes)
   unsigned int* dmax = (unsigned int*)((char*)workspace + 64);    // B
-  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, slamhip_prep_rgbd_workspace_bytes(B), s));
+  {
+    const long long words = (long long)(slamhip_prep_rgbd_workspace_bytes(B) / 4);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (unsigned int*)workspace, words);
+  }
   const long long hw = (long long)Hs * Ws;
   hipLaunchKernelGGL(depth_max_kernel, dim3((unsigned)((hw + 4095) / 4096 < 64 ? (hw + 4095) / 4096 : 64), B), dim3(256), 0,
                      s, depth, dmax, hw);
@@ -230,7 +240,10 @@ int slamhip_prep_rgbd_tf(const uint8_t* rgb, const uint16_t* depth, int B, int H
                   "prep_rgbd_tf: too many pixels");
   hipStream_t s = (hipStream_t)stream;
   unsigned int* dmax = (unsigned int*)((char*)workspace + 64);
-  SLAMHIP_HIP(hipMemsetAsync(workspace, 0, slamhip_prep_rgbd_workspace_bytes(B), s));
+  {
+    const long long words = (long long)(slamhip_prep_rgbd_workspace_bytes(B) / 4);
+    hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (unsigned int*)workspace, words);
+  }
   const long long total = (long long)B * Ho * Wo;
   hipLaunchKernelGGL(resize_rgbd_tf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rgb, depth, out_f32,
                      dmax, B, Hs, Ws, Ho, Wo);
