@@ -104,3 +104,19 @@ def test_stamp_past_the_ground_truth_raises_like_the_reference(tmp_path):
     gt_file.write_text("\n".join(rows[:-1]) + "\n")        # the last frame's stamp now lies past the ground truth
     with pytest.raises(IndexError):
         mi.get_simple_input_provider(lambda: ["seq"], base_data_dir=str(tmp_path))
+
+
+def test_host_reader_arithmetic_matches_the_oracle_restatement():
+    """model_input.py:437-450 (integer depth scaling, concatenation, order-1 resize): the product's host form
+    (gathers) against oracle/prep_oracle.py (interpolation matrices); parity unpinned, skimage is not installed."""
+    from oracle import prep_oracle
+    from slam_amd.utils import synthetic as syn
+    for (H, W, Ho, Wo) in ((48, 64, 22, 22), (37, 53, 16, 24), (20, 20, 20, 20), (9, 7, 30, 31)):
+        rgb = syn.rgb_frames(2, H, W, seed=H, kind="noise")
+        depth = syn.depth_frames(2, H, W, seed=W, kind="noise")
+        depth[1] = 0
+        for b in range(2):
+            d = depth[b].astype(np.int64)[..., None]
+            d = 255 * d // max(int(d.max()), 1)
+            got = mi.resize_bilinear(np.concatenate((rgb[b], d), 2), Ho, Wo).astype(np.float32)
+            np.testing.assert_allclose(got, prep_oracle.get_rgbd_file(rgb[b], depth[b], Ho, Wo), rtol=1e-6, atol=1e-4)
