@@ -57,7 +57,8 @@ def _order1_matrix(n_in, n_out):
 def resize_order1(img, out_h, out_w):
     img = np.asarray(img, np.float64)
     My, Mx = _order1_matrix(img.shape[0], out_h), _order1_matrix(img.shape[1], out_w)
-    return np.einsum("ah,hwc,bw->abc", My, img, Mx)
+    rows = np.tensordot(My, img, axes=(1, 0))                          # [out_h, W, C]
+    return np.tensordot(Mx, rows, axes=(1, 1)).transpose(1, 0, 2)      # [out_h, out_w, C]
 
 
 def get_rgbd_file(rgb_u8, depth_u16, out_h=224, out_w=224):
