@@ -156,40 +156,65 @@ subtract_mean_kernel(float* __restrict__ out, bf16_t* __restrict__ out_bf16, con
 __global__ void __launch_bounds__(256)
 resize_rgbd_tf_kernel(const uint8_t* __restrict__ rgb, const uint16_t* __restrict__ depth, float* __restrict__ out,
                       unsigned int* __restrict__ dmax_bits, int B, int Hs, int Ws, int Ho, int Wo) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)B * Ho * Wo) return;
-  const int xo = (int)(idx % Wo);
-  const int yo = (int)((idx / Wo) % Ho);
-  const int b = (int)(idx / ((long long)Wo * Ho));
-  const float in_y = (float)yo * ((float)Hs / (float)Ho), in_x = (float)xo * ((float)Ws / (float)Wo);
-  const int y0 = (int)floorf(in_y), x0 = (int)floorf(in_x);
-  const int y1 = min((int)ceilf(in_y), Hs - 1), x1 = min((int)ceilf(in_x), Ws - 1);
-  const float fy = in_y - (float)y0, fx = in_x - (float)x0;
-  const long long base = (long long)b * Hs * Ws;
-  const long long o00 = base + (long long)y0 * Ws + x0, o01 = base + (long long)y0 * Ws + x1;
-  const long long o10 = base + (long long)y1 * Ws + x0, o11 = base + (long long)y1 * Ws + x1;
+  // a workgroup covers 32 output columns x 32 output rows of one frame, a thread RS_ROWS consecutive rows of one
+  // column; the frame's maximum takes one atomic per workgroup
+  __shared__ unsigned int part[4];
+  const int b = blockIdx.z;
+  const int xo = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int yo0 = (blockIdx.y * 8 + (threadIdx.x >> 5)) * RS_ROWS;
+  unsigned int mbits = 0u;
+  if (xo < Wo) {
+    const float in_x = (float)xo * ((float)Ws / (float)Wo);
+    const int x0 = (int)floorf(in_x);
+    const int x1 = min((int)ceilf(in_x), Ws - 1);
+    const float fx = in_x - (float)x0;
+    const unsigned int plane = (unsigned int)b * (unsigned int)(Hs * Ws);   // (B Hs Ws < 2^32: checked by the host)
 #pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    float a, bq, cq, e;
-    if (c < 3) {
-      a = rgb[3 * o00 + c]; bq = rgb[3 * o01 + c]; cq = rgb[3 * o10 + c]; e = rgb[3 * o11 + c];
-    } else {
-      a = (float)(depth[o00] >> 8); bq = (float)(depth[o01] >> 8);
-      cq = (float)(depth[o10] >> 8); e = (float)(depth[o11] >> 8);
+    for (int j = 0; j < RS_ROWS; ++j) {
+      const int yo = yo0 + j;
+      if (yo >= Ho) break;
+      const float in_y = (float)yo * ((float)Hs / (float)Ho);
+      const int y0 = (int)floorf(in_y);
+      const int y1 = min((int)ceilf(in_y), Hs - 1);
+      const float fy = in_y - (float)y0;
+      const unsigned int r0 = plane + (unsigned int)(y0 * Ws), r1 = plane + (unsigned int)(y1 * Ws);
+      const unsigned int o00 = r0 + x0, o01 = r0 + x1, o10 = r1 + x0, o11 = r1 + x1;
+      const uint8_t *p00 = rgb + 3ull * o00, *p01 = rgb + 3ull * o01, *p10 = rgb + 3ull * o10, *p11 = rgb + 3ull * o11;
+      float4 res;
+      float* rp = &res.x;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float a, bq, cq, e;
+        if (c < 3) {
+          a = p00[c]; bq = p01[c]; cq = p10[c]; e = p11[c];
+        } else {
+          a = (float)(depth[o00] >> 8); bq = (float)(depth[o01] >> 8);
+          cq = (float)(depth[o10] >> 8); e = (float)(depth[o11] >> 8);
+        }
+        const float top = a + (bq - a) * fx, bot = cq + (e - cq) * fx;
+        rp[c] = top + (bot - top) * fy;
+      }
+      reinterpret_cast<float4*>(out)[((long long)b * Ho + yo) * Wo + xo] = res;
+      mbits = max(mbits, __float_as_uint(fmaxf(res.w, 0.0f)));   // (non-negative floats order like their bit patterns)
     }
-    const float top = a + (bq - a) * fx, bot = cq + (e - cq) * fx;
-    const float v = top + (bot - top) * fy;
-    out[idx * 4 + c] = v;
-    if (c == 3) atomicMax(&dmax_bits[b], __float_as_uint(fmaxf(v, 0.0f)));
+  }
+  for (int o = 32; o > 0; o >>= 1) mbits = max(mbits, (unsigned int)__shfl_xor((int)mbits, o));
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = mbits;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mbits = max(max(part[0], part[1]), max(part[2], part[3]));
+    if (mbits) atomicMax(&dmax_bits[b], mbits);
   }
 }
 
+// grid: (blocks over a frame's output pixels, frames)
 __global__ void __launch_bounds__(256)
-scale_depth_tf_kernel(float* __restrict__ out, const unsigned int* __restrict__ dmax_bits, long long total, int hw) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const float mx = __uint_as_float(dmax_bits[i / hw]);
-  out[4 * i + 3] = out[4 * i + 3] * 255.0f / mx;     // an all-zero depth image gives NaN, as in the reference
+scale_depth_tf_kernel(float* __restrict__ out, const unsigned int* __restrict__ dmax_bits, int hw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= hw) return;
+  const float mx = __uint_as_float(dmax_bits[blockIdx.y]);
+  float* o = out + 4 * ((long long)blockIdx.y * hw + i) + 3;
+  *o = *o * 255.0f / mx;     // an all-zero depth image gives NaN, as in the reference
 }
 
 }  // namespace slamhip
@@ -236,18 +261,18 @@ int slamhip_prep_rgbd_tf(const uint8_t* rgb, const uint16_t* depth, int B, int H
   SLAMHIP_REQUIRE(rgb && depth && out_f32 && workspace, SLAMHIP_E_ARG, "prep_rgbd_tf: null pointer");
   SLAMHIP_REQUIRE(workspace_bytes >= slamhip_prep_rgbd_workspace_bytes(B), SLAMHIP_E_SIZE,
                   "prep_rgbd_tf: workspace of %zu bytes, need %zu", workspace_bytes, slamhip_prep_rgbd_workspace_bytes(B));
-  SLAMHIP_REQUIRE((long long)Hs * Ws <= 0x7fffffffLL && (long long)B * Ho * Wo <= 0x7fffffffLL, SLAMHIP_E_SIZE,
-                  "prep_rgbd_tf: too many pixels");
+  SLAMHIP_REQUIRE((long long)Hs * Ws <= 0x7fffffffLL && (long long)B * Ho * Wo <= 0x7fffffffLL &&
+                      (long long)B * Hs * Ws <= 0xffffffffLL && B <= 65535,
+                  SLAMHIP_E_SIZE, "prep_rgbd_tf: too many pixels or frames (at most 2^32 source pixels and 65535 frames per call)");
   hipStream_t s = (hipStream_t)stream;
   unsigned int* dmax = (unsigned int*)((char*)workspace + 64);
   {
     const long long words = (long long)(slamhip_prep_rgbd_workspace_bytes(B) / 4);
     hipLaunchKernelGGL(clear_words_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, (unsigned int*)workspace, words);
   }
-  const long long total = (long long)B * Ho * Wo;
-  hipLaunchKernelGGL(resize_rgbd_tf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, rgb, depth, out_f32,
-                     dmax, B, Hs, Ws, Ho, Wo);
-  hipLaunchKernelGGL(scale_depth_tf_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out_f32, dmax, total,
+  hipLaunchKernelGGL(resize_rgbd_tf_kernel, dim3((unsigned)((Wo + 31) / 32), (unsigned)((Ho + 8 * RS_ROWS - 1) / (8 * RS_ROWS)), (unsigned)B),
+                     dim3(256), 0, s, rgb, depth, out_f32, dmax, B, Hs, Ws, Ho, Wo);
+  hipLaunchKernelGGL(scale_depth_tf_kernel, dim3((unsigned)((Ho * Wo + 255) / 256), (unsigned)B), dim3(256), 0, s, out_f32, dmax,
                      Ho * Wo);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
