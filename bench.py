@@ -398,7 +398,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%ssynthetic %dx%d depth+RGB pairs, batch %d anchors per GPU, "
                                    "backproject+warp+loss fused (k=%d neighbour%s), %s depth, factor %g"
-                                   % ("configs[1]: " if (k, H, W) == (1, 480, 640) else "", W, H, B, k,
+                                   % ("configs[1]: " if (B, k, H, W) == (64, 1, 480, 640) else "", W, H, B, k,
                                       "" if k == 1 else "s", a.depth, a.factor),
                        "pairs_per_gpu_per_step": B * k, "hbm_batches_rotated": len(bufs), "parallelism": "dp%d" % world,
                        "streams": max(1, a.streams), "ramp_ms": a.ramp_ms, "ramp_launches": ramp_launches, "post_barrier_launches": post_barrier_launches},
