@@ -12,12 +12,12 @@
 // borders matter here (no tap choice), so all but a few pixels in 10^6 are decided by the cheap form.
 //
 // Most pixels are not projected at all.  For a fixed depth the projection is a projective map of the pixel
-// coordinates with a positive denominator (z' > 0), which takes a wave's 64 x RPW rectangle to a convex
+// coordinates with a positive denominator (z' > 0), which takes a wave's 128 x RPW rectangle to a convex
 // quadrilateral, and as the depth of one pixel varies its projection moves along a segment; so every pixel of
 // the rectangle with a depth in [z_min, z_max] projects into the convex hull of the rectangle's four corners
 // taken at z_min and at z_max.  When these eight points lie inside the window by the certificate's margin
 // (or all beyond one of its borders by that margin), so does every pixel, in the reference's arithmetic too,
-// and the wave only counts its non-zero depths: 4 instead of 21 vector instructions per pixel.  Waves whose
+// and the wave only counts its non-zero depths: 2.5 instead of 21 vector instructions per pixel.  Waves whose
 // rectangle straddles a border project pixel by pixel.
 //
 // HBM-streaming by its bytes, bound by vector instructions; nothing GEMM-shaped, no MFMA.  Built with
@@ -26,11 +26,11 @@
 
 namespace slamhip {
 
-constexpr int OVL_TILE_W = 128;   // two waves side by side, a lane is an image column
+constexpr int OVL_TILE_W = 128;   // a wave's 64 lanes hold two columns each
 #ifndef SLAMHIP_OVL_RPW
-#define SLAMHIP_OVL_RPW 24
+#define SLAMHIP_OVL_RPW 15
 #endif
-constexpr int OVL_RPW = SLAMHIP_OVL_RPW;   // rows a lane walks; the tile's two wave rows give twice as many
+constexpr int OVL_RPW = SLAMHIP_OVL_RPW;   // rows a lane walks; the tile's four waves lie one below the other
 
 struct OvlArgs {
   Cam cam;
@@ -42,6 +42,7 @@ struct OvlArgs {
   int B, H, W;
   int cert_ok;             // the constants are mid-range: the cheap form may decide pixels
   int cx_col, cy_row;      // the column / row with col - cx == 0 / row - cy == 0, or -1
+  int pair_loads;          // W is even and the plane 4-byte aligned: a lane reads its two columns in one load
 };
 
 // Constants of the cheap projection that depend on the pair alone (wave-uniform).
@@ -76,6 +77,32 @@ __device__ __forceinline__ unsigned int wave_umax63(unsigned int v) {
   return v;
 }
 
+typedef unsigned short ovl_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ovl_u16x2 as_u16x2(unsigned int v) { return __builtin_bit_cast(ovl_u16x2, v); }
+__device__ __forceinline__ unsigned int as_u32(ovl_u16x2 v) { return __builtin_bit_cast(unsigned int, v); }
+__device__ __forceinline__ unsigned int pk_umin(unsigned int a, unsigned int b) {
+  return as_u32(__builtin_elementwise_min(as_u16x2(a), as_u16x2(b)));
+}
+__device__ __forceinline__ unsigned int pk_umax(unsigned int a, unsigned int b) {
+  return as_u32(__builtin_elementwise_max(as_u16x2(a), as_u16x2(b)));
+}
+__device__ __forceinline__ unsigned int pk_usub(unsigned int a, unsigned int b) { return as_u32(as_u16x2(a) - as_u16x2(b)); }
+__device__ __forceinline__ unsigned int pk_uadd(unsigned int a, unsigned int b) { return as_u32(as_u16x2(a) + as_u16x2(b)); }
+// sum over the wave, valid in lane 63
+__device__ __forceinline__ unsigned int wave_usum63(unsigned int v) {
+  v += ovl_dpp<0xB1, 0xF>(0u, v);
+  v += ovl_dpp<0x4E, 0xF>(0u, v);
+  v += ovl_dpp<0x141, 0xF>(0u, v);
+  v += ovl_dpp<0x140, 0xF>(0u, v);
+  v += ovl_dpp<0x142, 0xA>(0u, v);
+  v += ovl_dpp<0x143, 0xC>(0u, v);
+  return v;
+}
+
+// A workgroup is a tile of OVL_TILE_W columns x 4 OVL_RPW rows, a wave a rectangle of OVL_TILE_W x OVL_RPW, a lane two
+// neighbouring image columns: a row of the lane is one 32-bit register {depth of column c | depth of column c + 1 << 16},
+// read with one 4-byte load where the plane allows it, and the statistics of the whole-rectangle decision run on the
+// packed pairs.
 __global__ void __launch_bounds__(256)
 overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const double* __restrict__ rel,
                      unsigned int* __restrict__ counts) {
@@ -87,37 +114,47 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   const int b = blockIdx.z;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int col = blockIdx.x * OVL_TILE_W + (wave & 1) * 64 + lane;
-  const int row0 = blockIdx.y * (2 * RPW) + (wave >> 1) * RPW;
-  const int colc = min(col, W - 1);
+  const int wc0 = blockIdx.x * OVL_TILE_W;        // first column of the rectangle
+  const int col = wc0 + 2 * lane;                 // this lane's columns: col, col + 1
+  const int row0 = (blockIdx.y * 4 + wave) * RPW;
   const Pose p = load_pose(rel + 16 * (long long)b);
 
-  // this lane's pixels: raw depth, read once; nothing waits for the loads until the first row
+  // this lane's pixels: raw depth, read once; nothing waits for the loads until they are used.  Pixels outside
+  // the image count as depth 0 (only the tiles of the right and bottom edge have any).
   const uint16_t* d1b = depth + (long long)b * H * W;
   unsigned int a_d[RPW];
+  if (a.pair_loads) {   // W even and the plane 4-byte aligned: a lane's two columns are one aligned 32-bit word
+    const unsigned int cc = (unsigned int)min(col, W - 2);
 #pragma unroll
-  for (int r = 0; r < RPW; ++r) {
-    const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;   // (an image has at most 2^29 pixels)
-    a_d[r] = d1b[(size_t)rw + (unsigned int)colc];
-  }
-
-  // pixels outside the image count as depth 0 (only the tiles of the right and bottom edge have any)
-  if (col >= W) {
+    for (int r = 0; r < RPW; ++r) {
+      const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;   // (an image has at most 2^29 pixels)
+      a_d[r] = *reinterpret_cast<const unsigned int*>(d1b + (size_t)(rw + cc));
+    }
+    if (col >= W) {
 #pragma unroll
-    for (int r = 0; r < RPW; ++r) a_d[r] = 0u;
+      for (int r = 0; r < RPW; ++r) a_d[r] = 0u;
+    }
+  } else {
+    const unsigned int c0 = (unsigned int)min(col, W - 1), c1 = (unsigned int)min(col + 1, W - 1);
+    const unsigned int keep = (col < W ? 0xffffu : 0u) | (col + 1 < W ? 0xffff0000u : 0u);
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+      const unsigned int rw = (unsigned int)min(row0 + r, H - 1) * (unsigned int)W;
+      a_d[r] = ((unsigned int)d1b[(size_t)(rw + c0)] | ((unsigned int)d1b[(size_t)(rw + c1)] << 16)) & keep;
+    }
   }
   if (row0 + RPW > H) {
 #pragma unroll
     for (int r = 0; r < RPW; ++r) a_d[r] = (row0 + r < H) ? a_d[r] : 0u;
   }
-
-  // rows of this wave inside the image, and of those the rows with row - cy != 0
-  const int n_in = min(max(H - row0, 0), RPW);
-  const unsigned int rows_in = (1u << n_in) - 1u;     // RPW < 32
-  const unsigned int rz = (unsigned int)(a.cy_row - row0);
-  const unsigned int rows_nz = rows_in & ~((rz < (unsigned int)RPW) ? (1u << rz) : 0u);
-  const unsigned long long col_in = __builtin_amdgcn_ballot_w64(col < W);
-  const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(col < W && col != a.cx_col);
+  // points with x == 0 or y == 0 are dropped by _point_cloud: with an integer principal point the pixels of that
+  // column and of that row count as depth 0 as well
+  if (a.cx_col >= 0 || a.cy_row >= 0) {
+    const unsigned int e = (unsigned int)(a.cx_col - col);      // 0 / 1: this lane holds the column
+    const unsigned int keep = e == 0u ? 0xffff0000u : e == 1u ? 0x0000ffffu : 0xffffffffu;
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) a_d[r] = (row0 + r == a.cy_row) ? 0u : (a_d[r] & keep);
+  }
 
   // ---- certificate and constants (wave 0, while the others' loads are in flight) ----
   // With S = 65535/factor * (axm |r0j| + aym |r1j| + |r2j|) + |tj| (the largest sum of magnitudes in the
@@ -158,29 +195,27 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   const OvlConsts pc = s_c;
   const bool cert_u = __builtin_amdgcn_readfirstlane(pc.cert) != 0;
 
-  unsigned int n_valid0 = 0u, n_inb = 0u;   // wave-uniform counts of the decided pixels
-  unsigned int rest_bits = 0u;              // bit r: row r of this lane is left to the exact form
+  unsigned int n_valid0 = 0u, n_inb = 0u;     // wave-uniform counts of the decided pixels
+  unsigned int rest0 = 0u, rest1 = 0u;        // bit r: row r of this lane's first / second column is left to the exact form
 
   // ---- the wave's rectangle as a whole: depth range, number of kept points, the eight hull points ----
   bool whole = false;
   if (cert_u) {
-    unsigned int zmn = 0xffffffffu, zmx = 0u, n_kept = 0u;
+    unsigned int mn = 0xffffffffu, mx = 0u, cnt = 0u;
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const unsigned int draw = a_d[r];
-      zmn = min(zmn, draw - 1u);   // (depth 0 wraps to the identity of the minimum)
-      zmx = max(zmx, draw);
-      const unsigned long long m = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
-      n_kept += ((rows_nz >> r) & 1u) ? (unsigned int)__popcll(m) : 0u;
+      mn = pk_umin(mn, pk_usub(a_d[r], 0x00010001u));   // (depth 0 wraps to the identity of the minimum)
+      mx = pk_umax(mx, a_d[r]);
+      cnt = pk_uadd(cnt, pk_umin(a_d[r], 0x00010001u));
     }
-    const unsigned int z_lo = (unsigned int)__builtin_amdgcn_readlane((int)wave_umin63(zmn), 63) + 1u;
-    const unsigned int z_hi = (unsigned int)__builtin_amdgcn_readlane((int)wave_umax63(zmx), 63);
-    if (z_hi == 0u) {
+    const unsigned int n_kept = (unsigned int)__builtin_amdgcn_readlane((int)wave_usum63((cnt & 0xffffu) + (cnt >> 16)), 63);
+    const unsigned int z_lo = ((unsigned int)__builtin_amdgcn_readlane((int)wave_umin63(min(mn & 0xffffu, mn >> 16)), 63) + 1u) & 0xffffu;
+    const unsigned int z_hi = (unsigned int)__builtin_amdgcn_readlane((int)wave_umax63(max(mx & 0xffffu, mx >> 16)), 63);
+    if (n_kept == 0u) {
       whole = true;   // no depth at all: nothing kept
     } else {
       // lane l < 8: corner (l & 1 ? last : first column, l & 2 ? last : first row) at (l & 4 ? z_hi : z_lo)
-      const int wc0 = blockIdx.x * OVL_TILE_W + (wave & 1) * 64;
-      const double ccol = (double)((lane & 1) ? min(wc0 + 63, W - 1) : wc0) - a.cam.cx;
+      const double ccol = (double)((lane & 1) ? min(wc0 + OVL_TILE_W - 1, W - 1) : wc0) - a.cam.cx;
       const double crow = (double)((lane & 2) ? min(row0 + RPW - 1, H - 1) : row0) - a.cam.cy;
       const double z = (double)((lane & 4) ? z_hi : z_lo);
       const double Ac = fma(ccol, pc.kAc, fma(crow, pc.kAr, pc.kA0));
@@ -206,54 +241,67 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   if (whole) {
     // decided above
   } else if (cert_u) {
+    // ---- pixel by pixel: the cheap projection decides all but the pixels near a border ----
     const double ucx = (double)col - a.cam.cx, vcy0 = (double)row0 - a.cam.cy;
     double A = fma(ucx, pc.kAc, fma(vcy0, pc.kAr, pc.kA0));
     double Bq = fma(ucx, pc.kBc, fma(vcy0, pc.kBr, pc.kB0));
     double C = fma(ucx, pc.kCc, fma(vcy0, pc.kCr, pc.kC0));
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
-      const unsigned int draw = a_d[r];
-      const double z = (double)draw;
-      const double X = fma(z, A, pc.t0p), Y = fma(z, Bq, pc.t1p), Z = fma(z, C, pc.t2);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const unsigned int draw = e ? (a_d[r] >> 16) : (a_d[r] & 0xffffu);
+        const double Ae = e ? A + pc.kAc : A, Be = e ? Bq + pc.kBc : Bq, Ce = e ? C + pc.kCc : C;
+        const double z = (double)draw;
+        const double X = fma(z, Ae, pc.t0p), Y = fma(z, Be, pc.t1p), Z = fma(z, Ce, pc.t2);
+        double rcp = __builtin_amdgcn_rcp(Z);
+        rcp = fma(rcp, fma(-Z, rcp, 1.0), rcp);
+        const double du = fabs(fma(X, rcp, pc.cu)), dv = fabs(fma(Y, rcp, pc.cv));   // distance from the window's centre
+        const unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u);
+        const unsigned long long m_z = m_valid0 & __builtin_amdgcn_ballot_w64(Z > pc.dz);
+        const unsigned long long m_in = m_z & __builtin_amdgcn_ballot_w64(du < pc.in_u) & __builtin_amdgcn_ballot_w64(dv < pc.in_v);
+        const unsigned long long m_out = m_z & (__builtin_amdgcn_ballot_w64(du > pc.out_u) | __builtin_amdgcn_ballot_w64(dv > pc.out_v));
+        n_valid0 += (unsigned int)__popcll(m_in | m_out);
+        n_inb += (unsigned int)__popcll(m_in);
+        const unsigned long long m_rest = m_valid0 & ~(m_in | m_out);   // near a border, behind the camera, non-finite
+        if (m_rest != 0ull) {
+          const unsigned int bit = __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
+          if (e) rest1 |= bit; else rest0 |= bit;
+        }
+      }
       A += pc.kAr; Bq += pc.kBr; C += pc.kCr;
-      double rcp = __builtin_amdgcn_rcp(Z);
-      rcp = fma(rcp, fma(-Z, rcp, 1.0), rcp);
-      const double du = fabs(fma(X, rcp, pc.cu)), dv = fabs(fma(Y, rcp, pc.cv));   // distance from the window's centre
-      unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
-      if (!((rows_nz >> r) & 1u)) m_valid0 = 0ull;
-      const unsigned long long m_z = m_valid0 & __builtin_amdgcn_ballot_w64(Z > pc.dz);
-      const unsigned long long m_in = m_z & __builtin_amdgcn_ballot_w64(du < pc.in_u) & __builtin_amdgcn_ballot_w64(dv < pc.in_v);
-      const unsigned long long m_out = m_z & (__builtin_amdgcn_ballot_w64(du > pc.out_u) | __builtin_amdgcn_ballot_w64(dv > pc.out_v));
-      n_valid0 += (unsigned int)__popcll(m_in | m_out);
-      n_inb += (unsigned int)__popcll(m_in);
-      const unsigned long long m_rest = m_valid0 & ~(m_in | m_out);   // near a border, behind the camera, non-finite
-      if (m_rest != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
     }
   } else {
     // no certificate (constants out of range, a degenerate pose): every pixel in the image
-    rest_bits = __builtin_amdgcn_inverse_ballot_w64(col_in) ? rows_in : 0u;
+    const int n_in = min(max(H - row0, 0), RPW);
+    const unsigned int rows_in = (1u << n_in) - 1u;     // RPW < 32
+    rest0 = col < W ? rows_in : 0u;
+    rest1 = col + 1 < W ? rows_in : 0u;
   }
 
   // ---- the reference's exact operation order for the pixels left ----
-  if (__builtin_amdgcn_ballot_w64(rest_bits != 0u) != 0ull) {
+  if (__builtin_amdgcn_ballot_w64((rest0 | rest1) != 0u) != 0ull) {
     const double dim_u = 2.0 * a.half_u, dim_v = 2.0 * a.half_v;   // (exact: the halves are the host's dim / 2)
 #pragma unroll 1
     for (int r = 0; r < RPW; ++r) {
-      const bool need = (rest_bits >> r) & 1u;
-      if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
-      bool valid0 = false, inb = false;
-      if (need) {
-        const int row = row0 + r;
-        const unsigned int draw = d1b[(long long)row * W + col];
-        double x, y, z, x2, y2, z2, u, v;
-        backproject_px(a.cam, col, row, draw, x, y, z);
-        valid0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
-        transform_px(p, x, y, z, x2, y2, z2);
-        project_px(a.cam, x2, y2, z2, u, v);
-        inb = valid0 && in_window(u, v, dim_u, dim_v);
+#pragma unroll 1
+      for (int e = 0; e < 2; ++e) {
+        const bool need = ((e ? rest1 : rest0) >> r) & 1u;
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) continue;
+        bool valid0 = false, inb = false;
+        if (need) {
+          const int row = row0 + r, cole = col + e;
+          const unsigned int draw = d1b[(long long)row * W + cole];
+          double x, y, z, x2, y2, z2, u, v;
+          backproject_px(a.cam, cole, row, draw, x, y, z);
+          valid0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
+          transform_px(p, x, y, z, x2, y2, z2);
+          project_px(a.cam, x2, y2, z2, u, v);
+          inb = valid0 && in_window(u, v, dim_u, dim_v);
+        }
+        n_valid0 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(valid0));
+        n_inb += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(inb));
       }
-      n_valid0 += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(valid0));
-      n_inb += (unsigned int)__popcll(__builtin_amdgcn_ballot_w64(inb));
     }
   }
 
@@ -280,7 +328,7 @@ extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4
   SLAMHIP_REQUIRE((reinterpret_cast<uintptr_t>(depth) % 2) == 0 && (reinterpret_cast<uintptr_t>(rel4x4) % 8) == 0 &&
                       (reinterpret_cast<uintptr_t>(counts) % 4) == 0,
                   SLAMHIP_E_ARG, "overlap_fused: misaligned input or output");
-  const int tiles_x = (W + OVL_TILE_W - 1) / OVL_TILE_W, tiles_y = (H + 2 * OVL_RPW - 1) / (2 * OVL_RPW);
+  const int tiles_x = (W + OVL_TILE_W - 1) / OVL_TILE_W, tiles_y = (H + 4 * OVL_RPW - 1) / (4 * OVL_RPW);
   SLAMHIP_REQUIRE(B <= 65535 && tiles_y <= 65535, SLAMHIP_E_SIZE, "overlap_fused: more than 65535 pairs per call");
   hipStream_t s = (hipStream_t)stream;
   OvlArgs a;
@@ -303,6 +351,7 @@ extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4
   auto int_index = [](double c, int n) { return (c >= 0.0 && c < (double)n && c == floor(c)) ? (int)c : -1; };
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
+  a.pair_loads = (W % 2 == 0) && W >= 2 && (reinterpret_cast<uintptr_t>(depth) % 4) == 0;
   // the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds kernel nodes only)
   clear_u32_async(counts, 2LL * B, s);
   hipLaunchKernelGGL(overlap_fused_kernel, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)B), dim3(256), 0, s, a,
