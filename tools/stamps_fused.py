@@ -15,7 +15,7 @@ rel = fp.relative_pose(gt[:, 0].contiguous(), gt[:, 1].contiguous()).reshape(B, 
 x = [torch.from_numpy(a).cuda() for a in (syn.depth_frames(B, H, W, seed=1, kind="plane"), syn.rgb_frames(B, H, W, seed=1),
                                            syn.depth_frames(B, H, W, seed=2, kind="plane"), syn.rgb_frames(B, H, W, seed=2))]
 lib = capi.load()
-nwg = 8192
+nwg = 16384   # at least the launch's workgroups (9 600 on 128 x 16 tiles)
 stamps = torch.zeros((nwg, 16), dtype=torch.int64, device="cuda")
 lib.slamhip_debug_set_stamps.argtypes = [ctypes.c_void_p]
 lib.slamhip_debug_set_stamps(None)
@@ -57,3 +57,7 @@ for a in np.arange(0.0, span, 4.0):
     resident = np.clip(np.minimum(en, b) - np.maximum(st, a), 0, None).sum() / 4.0
     started = (st >= a) & (st < b)
     print("%8.0f | %8.1f | %5d | %s" % (a, resident, started.sum(), "%.2f" % (en[started] - st[started]).mean() if started.any() else "-"))
+# the fill of the launch in 0.5 us bins: workgroups started and finished so far
+print("fill: time us | started so far | finished so far")
+for a in np.arange(0.5, 12.01, 0.5):
+    print("%6.1f | %5d | %5d" % (a, (st < a).sum(), (en < a).sum()))
