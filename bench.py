@@ -287,7 +287,9 @@ def main():
             torch.cuda.synchronize()
             call_ms = o0.elapsed_time(o1) / n_ovl
             last_i = ((n_ovl - 1) % n_copies) % len(bufs)
-            same = bool(torch.equal(oc, plans[last_i].run()[1].reshape(B, -1)[:, :2].to(torch.int32)))
+            fused_counts = plans[last_i].run()[1]
+            torch.cuda.synchronize()       # (a plan may launch on a side stream)
+            same = bool(torch.equal(oc, fused_counts.reshape(B, -1)[:, :2].to(torch.int32)))
             ovl_bytes = B * H * W * 2
             overlap = {"workload": "slamhip_overlap_fused on the %d anchor depth planes of a batch (counts of _point_cloud -> "
                                    "_transform_pointcloud -> _backtransform_pointcloud -> _overlap, no intermediates)" % B,
