@@ -253,6 +253,22 @@ int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* 
                                     const float* beta, float* red2c, const void* x, float* dw, int B, int H,
                                     int W, float eps, void* stream);
 
+/* The first layer (4 input channels, 64 filters, batch-norm, no pool; cnn_model.py:37,100-113) without a
+ * stored z.  Forward: one pass for the channel statistics of z (sums2c, as slamhip_conv3x3_small_fwd_stats),
+ * a second pass that recomputes z and writes y = relu(batch-norm(z)) only: the values of
+ * slamhip_conv3x3_small_fwd_stats + slamhip_bn_relu_fwd bit for bit, for one tensor write instead of two
+ * writes and a read.  workspace: slamhip_conv_stats_workspace_bytes(B*H*W, 64) bytes. */
+int slamhip_conv3x3_c4_bn_relu_fwd(const void* x, const float* w_hwio, const float* gamma, const float* beta,
+                                   void* y_bf16, float* sums2c, void* workspace, size_t workspace_bytes, int B,
+                                   int H, int W, float eps, void* stream);
+/* Backward of that layer, as slamhip_bn_relu_bwd_first_layer, with z recomputed from x and the filter inside
+ * both passes instead of read (same values: the forward's operand order).  workspace: 512 bytes per 64 * ceil(
+ * ceil(B*H*W / 2048) / 64) pixels, at most 1 MB. */
+int slamhip_bn_relu_bwd_first_layer_recompute(const void* dy, const void* x, const float* w_hwio,
+                                              const float* sums2c, const float* gamma, const float* beta,
+                                              float* red2c, float* dw, void* workspace, size_t workspace_bytes,
+                                              int B, int H, int W, float eps, void* stream);
+
 /* The two calls above fused with the 2x2 stride-2 max-pool that follows the last
  * layer of every block (cnn_model.py:40,45,50,56,62).  Forward: z [B,H,W,C] -> y (same
  * shape; NULL = not written, nothing downstream of a pooled layer reads it) and

@@ -61,6 +61,9 @@ SIGNATURES = {
     "slamhip_conv3x3_small_fwd": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p], _c_int),
     "slamhip_conv3x3_small_wgrad": ([_c_void_p] * 3 + [_c_int] * 5 + [_c_void_p], _c_int),
     "slamhip_bn_relu_bwd_first_layer": ([_c_void_p] * 8 + [_c_int] * 3 + [ctypes.c_float, _c_void_p], _c_int),
+    "slamhip_conv3x3_c4_bn_relu_fwd": ([_c_void_p] * 7 + [ctypes.c_size_t] + [_c_int] * 3 + [ctypes.c_float, _c_void_p], _c_int),
+    "slamhip_bn_relu_bwd_first_layer_recompute": ([_c_void_p] * 9 + [ctypes.c_size_t] + [_c_int] * 3 +
+                                                  [ctypes.c_float, _c_void_p], _c_int),
     "slamhip_channel_stats": ([_c_void_p, _c_void_p, ctypes.c_longlong, _c_int, _c_void_p], _c_int),
     "slamhip_bn_relu_fwd": ([_c_void_p] * 5 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p], _c_int),
     "slamhip_bn_relu_bwd": ([_c_void_p] * 7 + [ctypes.c_longlong, _c_int, ctypes.c_float, _c_void_p], _c_int),

@@ -1138,9 +1138,16 @@ conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ 
 __device__ __forceinline__ uint2 and2(uint2 v, uint32_t keep) { return make_uint2(v.x & keep, v.y & keep); }
 
 // forward: 128 pixels x 64 filters per workgroup, one K-step
+//   MODE 0: out = z (bfloat16), column statistics of z when stat_part is given
+//   MODE 1: the column statistics alone, nothing is stored (first of two passes when z is not kept)
+//   MODE 2: out = y = relu(batch-norm(z)) with the statistics in `sums` (second pass): z is rounded to bfloat16
+//           and normalised with the operations of bn_relu_fwd_kernel, so y equals what that kernel makes of a
+//           stored z, bit for bit; the layer costs one write of y instead of a write and a read of z plus y
+template <int MODE>
 __global__ void __launch_bounds__(256)
 conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ Wt, bf16* __restrict__ out, int P,
-                          int H, int W, float* __restrict__ stat_part, int tiles) {
+                          int H, int W, float* __restrict__ stat_part, int tiles, const float* __restrict__ sums,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float inv_count, float eps) {
   __shared__ __attribute__((aligned(16))) bf16 As[128 * LDS_PITCH];
   __shared__ __attribute__((aligned(16))) bf16 Bs[64 * LDS_PITCH];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1161,6 +1168,14 @@ conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ 
   const uint2* Xp = reinterpret_cast<const uint2*>(X);   // one pixel = 4 bf16 = 8 bytes
   uint2 v[5];
   uint32_t keep[5];
+  float bn_mean = 0.f, bn_r = 0.f, bn_beta = 0.f;        // MODE 2: a lane's accumulators all belong to one channel
+  if (MODE == 2) {
+    const int c = wn * 32 + (lane & 31);
+    bn_mean = sums[c] * inv_count;
+    const float var = fmaxf(sums[64 + c] * inv_count - bn_mean * bn_mean, 0.0f);
+    bn_r = gamma[c] * rsqrtf(var + eps);
+    bn_beta = beta[c];
+  }
 #define SLAMHIP_C4_FETCH(tile)                                                                              \
   {                                                                                                         \
     const int m0f = (tile) * 128;                                                                           \
@@ -1207,20 +1222,25 @@ conv3x3_c4_k64_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ 
     }
     // the output tile goes through LDS (the im2col rows are no longer needed) so that it leaves
     // in 16-byte stores of whole 128-byte pixel rows instead of 2-byte stores
-    __syncthreads();
+    if (MODE != 1) {
+      __syncthreads();
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        As[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_PITCH + wn * 32 + (lane & 31)] = (bf16)acc[i][r];
-    __syncthreads();
+        for (int r = 0; r < 16; ++r) {
+          bf16 o = (bf16)acc[i][r];
+          if (MODE == 2) o = (bf16)fmaxf(__builtin_fmaf((float)o - bn_mean, bn_r, bn_beta), 0.0f);
+          As[(wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * LDS_PITCH + wn * 32 + (lane & 31)] = o;
+        }
+      __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int id = tid + 256 * k, orow = id >> 3, c8 = id & 7;
-      if (m0 + orow < P)
-        *reinterpret_cast<uint4*>(out + (long long)(m0 + orow) * 64 + c8 * 8) = *reinterpret_cast<const uint4*>(&As[orow * LDS_PITCH + c8 * 8]);
+      for (int k = 0; k < 4; ++k) {
+        const int id = tid + 256 * k, orow = id >> 3, c8 = id & 7;
+        if (m0 + orow < P)
+          *reinterpret_cast<uint4*>(out + (long long)(m0 + orow) * 64 + c8 * 8) = *reinterpret_cast<const uint4*>(&As[orow * LDS_PITCH + c8 * 8]);
+      }
     }
-    if (stat_part) {
+    if (MODE != 2 && stat_part) {
       float sm = 0.f, sq = 0.f;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -1349,6 +1369,153 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
   for (int r = 0; r < 16; ++r) {
     const int k = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     if (k < 36) atomicAdd(&dW[k * 64 + wn * 32 + (lane & 31)], acc[r]);
+  }
+}
+
+// Backward of the first layer WITHOUT its z tensor.  The filter gradient stages the im2col rows of every pixel
+// anyway, so z is recomputed from them per 64-pixel step: three MFMAs per wave with the forward kernel's operands
+// and order (pixels as A, the bfloat16 filter as B, k = 0, 16, 32), i.e. the forward's values.  In the accumulator
+// layout a lane's sixteen values belong to ONE channel, so the gate and the batch-norm backward need one set of
+// coefficients per lane; dy is staged in LDS as it comes from memory (16-byte loads) and every lane reads, and in
+// PHASE 1 overwrites with dz, the sixteen 2-byte entries that match its accumulators.  The 822 MB of z at batch 128
+// are then neither written by the forward pass nor read by the two backward passes.
+//   PHASE 0: one record of 128 floats per workgroup: sum g and sum g * xhat per channel, g = dy gated by y > 0
+//            (channel_reduce_kernel<1>'s quantities; the records are added by stat_finish_kernel)
+//   PHASE 1: dW += A^T dz with dz = batch-norm backward of g (bn_relu_bwd_apply_kernel's operations and rounding)
+template <int PHASE>
+__global__ void __launch_bounds__(256)
+conv3x3_c4_k64_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, const float* __restrict__ Wt,
+                          float* __restrict__ dW, float* __restrict__ red_part, int P, int H, int W,
+                          int px_per_block, const float* __restrict__ sums, const float* __restrict__ red,
+                          const float* __restrict__ gamma, const float* __restrict__ beta, float inv_count,
+                          float eps) {
+  constexpr int PX = 64 + 32;   // conflict-free pitch of the transposing reads (see wgrad_bf16_kernel)
+  __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];          // im2col rows [pixel][k]
+  __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PX];          // dy, then dz [pixel][channel]
+  __shared__ __attribute__((aligned(16))) bf16 Bs[64 * LDS_PITCH];   // filter [channel][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;     // wave: pixels wm * 32 ..., channels wn * 32 ... of the step
+  const long long p_begin_l = (long long)blockIdx.x * px_per_block;
+  if (p_begin_l >= P) return;
+  const int p_begin = (int)p_begin_l, p_end = min(P, p_begin + px_per_block);
+  const int l_row = tid >> 2, l_q = tid & 3;   // loader: pixel of the 64-pixel step, quarter of its row
+  const uint2* Xp = reinterpret_cast<const uint2*>(X);
+  const int hw = H * W;
+  {   // B[n][k] = filter[k][n] (k = tap * 4 + channel), zero for k >= 36, as the forward kernel builds it
+    const int n = tid & 63, kg = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = kg * 16 + i;
+      Bs[n * LDS_PITCH + k] = (bf16)(k < 36 ? Wt[k * 64 + n] : 0.0f);
+    }
+  }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+  uint2 xv[3];
+  uint4 yv[2];
+  uint32_t keep_x[3], keep_y = 0u;
+  // this lane's channel: column wn * 32 + (lane & 31) of the z tile
+  const int c = wn * 32 + (lane & 31);
+  const float mean = sums[c] * inv_count;
+  const float rstd = rsqrtf(fmaxf(sums[64 + c] * inv_count - mean * mean, 0.0f) + eps);
+  const float rr = gamma[c] * rstd, bet = beta[c];
+  const float k1 = PHASE == 1 ? red[c] * inv_count : 0.f;
+  const float k2 = PHASE == 1 ? rstd * (red[64 + c] * inv_count) : 0.f;
+  float s0 = 0.f, s1 = 0.f;
+  // entry of accumulator r in the dy / dz tile: row wm * 32 + (r & 3) + 8 (r >> 2) + 4 (lane >> 5), column c
+  bf16* const my_y = &Ys[(wm * 32 + 4 * (lane >> 5)) * PX + c];
+
+#define SLAMHIP_C4B_ISSUE(p0)                                                                   \
+  {                                                                                             \
+    const int p = (p0) + l_row;                                                                 \
+    const bool in_slice = p < p_end;                                                            \
+    const int pc = in_slice ? p : p_end - 1;                                                    \
+    const int rem = pc % hw, y = rem / W, x = rem - y * W;                                      \
+    _Pragma("unroll") for (int i = 0; i < 3; ++i) {                                             \
+      const int t = l_q * 3 + i;                        /* quarter 3 owns no tap: zeros */      \
+      const int dy = t / 3 - 1, dx = t % 3 - 1;                                                 \
+      const bool ok = in_slice && t < 9 && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W; \
+      xv[i] = Xp[ok ? pc + dy * W + dx : pc];                                                   \
+      keep_x[i] = ok ? 0xffffffffu : 0u;                                                        \
+    }                                                                                           \
+    const uint4* ys = reinterpret_cast<const uint4*>(dY + (long long)pc * 64 + l_q * 16);       \
+    yv[0] = ys[0]; yv[1] = ys[1];                                                               \
+    keep_y = in_slice ? 0xffffffffu : 0u;                                                       \
+  }
+
+  SLAMHIP_C4B_ISSUE(p_begin);
+  for (int p0 = p_begin; p0 < p_end; p0 += 64) {
+    __syncthreads();          // the previous step's reads of Xs and Ys are done (and Bs is written)
+    {
+      uint2* xd = reinterpret_cast<uint2*>(&Xs[l_row * PX]);
+      // quarters 0..2 write taps 3q..3q+2 (k = 12q ... 12q+11); quarter 3 the zero tail k = 36..63
+      if (l_q < 3) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xd[l_q * 3 + i] = and2(xv[i], keep_x[i]);
+      } else {
+#pragma unroll
+        for (int i = 9; i < 16; ++i) xd[i] = make_uint2(0u, 0u);
+      }
+      uint4* yd = reinterpret_cast<uint4*>(&Ys[l_row * PX + l_q * 16]);     // rows beyond the slice: dy = 0
+      yd[0] = and4(yv[0], keep_y); yd[1] = and4(yv[1], keep_y);
+    }
+    __syncthreads();
+    if (p0 + 64 < p_end) SLAMHIP_C4B_ISSUE(p0 + 64);
+    f32x16 zacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zacc[r] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < 48; kk += 16) {   // k >= 48 is all zeros
+      const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(&Bs[(wn * 32 + (lane & 31)) * LDS_PITCH + kk + 8 * (lane >> 5)]);
+      const bf16x8 af = *reinterpret_cast<const bf16x8*>(&Xs[(wm * 32 + (lane & 31)) * PX + kk + 8 * (lane >> 5)]);
+      zacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr, zacc, 0, 0, 0);
+    }
+    const bool rows_in = p0 + wm * 32 + 32 <= p_end;   // PHASE 1: dz of rows beyond the slice must stay zero
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      bf16* const e = my_y + ((r & 3) + 8 * (r >> 2)) * PX;
+      const float d = (float)(bf16)zacc[r] - mean;
+      const float g = (__builtin_fmaf(d, rr, bet) > 0.0f) ? (float)*e : 0.0f;   // forward's y > 0
+      if (PHASE == 1) {
+        const bool in = rows_in || p0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) < p_end;
+        *e = in ? (bf16)(rr * ((g - k1) - d * k2)) : (bf16)0.0f;
+      } else {
+        s0 += g;
+        s1 = __builtin_fmaf(g, d, s1);      // times rstd at the end
+      }
+    }
+    if (PHASE == 1) {
+      __syncthreads();
+#pragma unroll
+      for (int kk = 0; kk < 64; kk += 16) {
+        const bf16x8 af = tr_frag<PX>(Xs, kk, wm * 32, lane);   // A[m = k-index][k = pixel]
+        const bf16x8 bf = tr_frag<PX>(Ys, kk, wn * 32, lane);   // B[k = pixel][n = filter]
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+      }
+    }
+  }
+#undef SLAMHIP_C4B_ISSUE
+  if (PHASE == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (k < 36) atomicAdd(&dW[k * 64 + wn * 32 + (lane & 31)], acc[r]);
+    }
+  } else {
+    // lanes l and l + 32 hold the same channel; the two pixel halves (waves wm = 0, 1) meet in LDS, in a fixed order
+    s1 *= rstd;                                         // sum g d -> sum g xhat
+    s0 += __shfl_xor(s0, 32);
+    s1 += __shfl_xor(s1, 32);
+    __syncthreads();                                    // the last step's reads of Ys are done
+    float* part = reinterpret_cast<float*>(Ys);         // [wm][which][64 channels]
+    if (lane < 32) {
+      part[(wm * 2 + 0) * 64 + c] = s0;
+      part[(wm * 2 + 1) * 64 + c] = s1;
+    }
+    __syncthreads();
+    if (tid < 128)            // record[c] = sum g, record[64 + c] = sum g xhat
+      red_part[(long long)blockIdx.x * 128 + tid] = part[tid] + part[128 + tid];
   }
 }
 
@@ -2070,6 +2237,23 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
   return (M + 127) / 128 * 2;
 }
 
+// Grid of the first layer's forward kernel, whose workgroups walk the pixel tiles: as many workgroups as the chip
+// holds at once (a grid of 2048 on 1280 slots ran a second, 60 % full round)
+template <int MODE>
+static int c4_fwd_grid(int tiles) {
+  static const int slots = [] {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3x3_c4_k64_fwd_kernel<MODE>, 256, 0) != hipSuccess ||
+        per_cu <= 0)
+      per_cu = 4;
+    return cus * per_cu;
+  }();
+  return tiles < slots ? tiles : slots;
+}
+
 }  // namespace slamhip
 
 using namespace slamhip;
@@ -2248,8 +2432,9 @@ static int small_fwd(const void* x, const float* w_hwio, void* out_bf16, int B, 
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
     const int tiles = (P + 127) / 128;
-    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel, dim3(tiles < 2048 ? tiles : 2048), dim3(256), 0, s, (const bf16*)x,
-                       w_hwio, (bf16*)out_bf16, P, H, W, stat_part, tiles);
+    hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel<0>, dim3(c4_fwd_grid<0>(tiles)), dim3(256), 0, s, (const bf16*)x,
+                       w_hwio, (bf16*)out_bf16, P, H, W, stat_part, tiles, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, 0.0f, 0.0f);
   } else {
     hipLaunchKernelGGL(conv3x3_small_fwd_kernel, dim3(blocks_for(total)), dim3(256), 0, s, (const bf16*)x, w_hwio,
                        (bf16*)out_bf16, P, H, W, Cin, Cout);
@@ -2383,6 +2568,59 @@ int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* 
   hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<true>, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0, s,
                      (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block, (const bf16*)z, sums2c,
                      (const float*)red2c, gamma, beta, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv3x3_c4_bn_relu_fwd(const void* x, const float* w_hwio, const float* gamma, const float* beta,
+                                   void* y_bf16, float* sums2c, void* workspace, size_t workspace_bytes, int B, int H,
+                                   int W, float eps, void* stream) {
+  SLAMHIP_REQUIRE(x && w_hwio && gamma && beta && y_bf16 && sums2c && workspace && B > 0 && H > 0 && W > 0,
+                  SLAMHIP_E_ARG, "conv3x3_c4_bn_relu_fwd: bad argument");
+  const long long Pl = (long long)B * H * W;
+  SLAMHIP_REQUIRE(Pl <= 0x7fffffffLL / 64, SLAMHIP_E_SIZE, "conv3x3_c4_bn_relu_fwd: too many pixels");
+  SLAMHIP_REQUIRE(workspace_bytes >= slamhip_conv_stats_workspace_bytes(Pl, 64), SLAMHIP_E_SIZE,
+                  "conv3x3_c4_bn_relu_fwd: workspace of %zu bytes, need %zu", workspace_bytes,
+                  slamhip_conv_stats_workspace_bytes(Pl, 64));
+  const int P = (int)Pl, tiles = (P + 127) / 128;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel<1>, dim3(c4_fwd_grid<1>(tiles)), dim3(256), 0, s, (const bf16*)x, w_hwio, (bf16*)nullptr, P, H,
+                     W, (float*)workspace, tiles, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                     0.0f, 0.0f);
+  SLAMHIP_HIP(hipGetLastError());
+  const int rc = finish_stats((const float*)workspace, sums2c, (Pl + 127) / 128 * 2, 64, s);
+  if (rc != SLAMHIP_OK) return rc;
+  hipLaunchKernelGGL(conv3x3_c4_k64_fwd_kernel<2>, dim3(c4_fwd_grid<2>(tiles)), dim3(256), 0, s, (const bf16*)x, w_hwio, (bf16*)y_bf16, P, H,
+                     W, (float*)nullptr, tiles, (const float*)sums2c, gamma, beta, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_bn_relu_bwd_first_layer_recompute(const void* dy, const void* x, const float* w_hwio,
+                                              const float* sums2c, const float* gamma, const float* beta,
+                                              float* red2c, float* dw, void* workspace, size_t workspace_bytes,
+                                              int B, int H, int W, float eps, void* stream) {
+  SLAMHIP_REQUIRE(dy && x && w_hwio && sums2c && gamma && beta && red2c && dw && workspace && B > 0 && H > 0 && W > 0,
+                  SLAMHIP_E_ARG, "bn_relu_bwd_first_layer_recompute: bad argument");
+  const long long Pl = (long long)B * H * W;
+  SLAMHIP_REQUIRE(Pl <= 0x7fffffffLL / 64, SLAMHIP_E_SIZE, "bn_relu_bwd_first_layer_recompute: too many pixels");
+  const int P = (int)Pl, C = 64;
+  const int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
+  const int blocks = (P + px_per_block - 1) / px_per_block;
+  SLAMHIP_REQUIRE(workspace_bytes >= sizeof(float) * 128 * (size_t)blocks, SLAMHIP_E_SIZE,
+                  "bn_relu_bwd_first_layer_recompute: workspace of %zu bytes, need %zu", workspace_bytes,
+                  sizeof(float) * 128 * (size_t)blocks);
+  hipStream_t s = (hipStream_t)stream;
+  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * 4 * (size_t)C, s));
+  hipLaunchKernelGGL(conv3x3_c4_k64_bwd_kernel<0>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
+                     w_hwio, (float*)nullptr, (float*)workspace, P, H, W, px_per_block, sums2c, (const float*)nullptr,
+                     gamma, beta, 1.0f / (float)P, eps);
+  SLAMHIP_HIP(hipGetLastError());
+  const int rc = finish_stats((const float*)workspace, red2c, blocks, C, s);
+  if (rc != SLAMHIP_OK) return rc;
+  hipLaunchKernelGGL(conv3x3_c4_k64_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
+                     w_hwio, dw, (float*)nullptr, P, H, W, px_per_block, sums2c, (const float*)red2c, gamma, beta,
+                     1.0f / (float)P, eps);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }

@@ -237,6 +237,10 @@ class VGG16Model:
         self.trace = None      # set to a dict to keep per-layer gradient copies (tests, debugging)
         # SLAM_FUSE_FIRST_BWD=0: the first layer's backward as two separate calls through dz
         self.fuse_first_backward = os.environ.get("SLAM_FUSE_FIRST_BWD", "1") not in ("", "0")
+        # the first layer without a stored z: its forward writes y alone and its backward recomputes z from the
+        # 4-channel input (SLAM_FIRST_RECOMPUTE=0: z is written and read as in every other layer)
+        self.first_layer_recompute = (os.environ.get("SLAM_FIRST_RECOMPUTE", "1") not in ("", "0")
+                                      and self.batch_norm and cin == 4 and not CONV_LAYERS[0][2])
         # True (or SLAM_KEEP_FULL_Y=1): pooled batch-norm layers also write their full-resolution output
         self.keep_full_y = os.environ.get("SLAM_KEEP_FULL_Y", "0") not in ("", "0")
         self._built = True
@@ -367,6 +371,12 @@ class VGG16Model:
         """The normalisation statistics are exchanged between the ranks in this pass."""
         return self.sync_batch_norm and dp.initialised() and dp.world_size() > 1
 
+    def _recompute_first(self):
+        """The first layer runs without its z tensor in this pass (not under tracing, which keeps z, nor with
+        statistics exchanged between ranks, whose backward runs in separate phases)."""
+        return (self.first_layer_recompute and self.fuse_first_backward and self.trace is None
+                and not self._sync_stats())
+
     def _refresh_operands(self):
         for a in self._act[1:]:
             n = a["name"]
@@ -388,6 +398,12 @@ class VGG16Model:
         h = self._x
         for i, a in enumerate(self._act):
             n = a["name"]
+            if i == 0 and self._recompute_first():
+                bn = self.params[n + "/bn"]
+                ops.conv3x3_c4_bn_relu(h, self.params[n + "/weights"], bn[1], bn[0], a["y"], a["sums"], self._stats_ws,
+                                       self.epsilon)
+                h = a["y"]
+                continue
             if self.batch_norm:     # the channel statistics come out of the convolution's epilogue
                 if i == 0:
                     ops.conv3x3_small_stats(h, self.params[n + "/weights"], a["z"], a["sums"], self._stats_ws)
@@ -500,8 +516,13 @@ class VGG16Model:
                     and a["z"].shape[-1] == 64 and self._x.shape[-1] == 4 and not sync):
                 # first layer: its dz has one reader, the filter gradient, which computes it on the way
                 bn = self.params[n + "/bn"]
-                ops.bn_relu_bwd_first_layer(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], self._x,
-                                            self.grads[n + "/weights"], self.epsilon)
+                if self._recompute_first():
+                    ops.bn_relu_bwd_first_layer_recompute(g, self._x, self.params[n + "/weights"], a["sums"], bn[1],
+                                                          bn[0], self.grads[n + "/bn"], self.grads[n + "/weights"],
+                                                          self._stats_ws, self.epsilon)
+                else:
+                    ops.bn_relu_bwd_first_layer(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], self._x,
+                                                self.grads[n + "/weights"], self.epsilon)
                 continue
             if self.batch_norm:
                 bn = self.params[n + "/bn"]

@@ -134,6 +134,28 @@ def bn_relu_bwd_first_layer(dy, z, sums2c, gamma, beta, red2c, x, dw, eps):
           capi.ptr(beta), capi.ptr(red2c), capi.ptr(x), capi.ptr(dw), B, H, W, float(eps))
 
 
+def conv3x3_c4_bn_relu(x, w_hwio, gamma, beta, y, sums2c, workspace, eps):
+    """First layer (4 -> 64 channels) forward without a stored z: statistics pass, then y = relu(bn(conv(x)))."""
+    B, H, W, cin = _chk(x, BF16, "x").shape
+    assert cin == 4 and _chk(w_hwio, F32, "w").shape == (3, 3, 4, 64) and _chk(y, BF16, "y").shape == (B, H, W, 64)
+    assert _chk(sums2c, F32, "sums").shape == (2, 64) and workspace.is_cuda and workspace.is_contiguous()
+    assert _chk(gamma, F32, "gamma").shape == (64,) and _chk(beta, F32, "beta").shape == (64,)
+    _call("slamhip_conv3x3_c4_bn_relu_fwd", capi.ptr(x), capi.ptr(w_hwio), capi.ptr(gamma), capi.ptr(beta), capi.ptr(y),
+          capi.ptr(sums2c), capi.ptr(workspace), workspace.numel() * workspace.element_size(), B, H, W, float(eps))
+
+
+def bn_relu_bwd_first_layer_recompute(dy, x, w_hwio, sums2c, gamma, beta, red2c, dw, workspace, eps):
+    """bn_relu_bwd_first_layer with z recomputed from x and the filter instead of read."""
+    B, H, W, cin = _chk(x, BF16, "x").shape
+    assert cin == 4 and _chk(dy, BF16, "dy").shape == (B, H, W, 64) and _chk(w_hwio, F32, "w").shape == (3, 3, 4, 64)
+    assert _chk(sums2c, F32, "sums").shape == (2, 64) and _chk(red2c, F32, "red").shape == (2, 64)
+    assert _chk(gamma, F32, "gamma").shape == (64,) and _chk(beta, F32, "beta").shape == (64,)
+    assert _chk(dw, F32, "dw").shape == (3, 3, 4, 64) and workspace.is_cuda and workspace.is_contiguous()
+    _call("slamhip_bn_relu_bwd_first_layer_recompute", capi.ptr(dy), capi.ptr(x), capi.ptr(w_hwio), capi.ptr(sums2c),
+          capi.ptr(gamma), capi.ptr(beta), capi.ptr(red2c), capi.ptr(dw), capi.ptr(workspace),
+          workspace.numel() * workspace.element_size(), B, H, W, float(eps))
+
+
 def bn_relu_pool(z, sums2c, gamma, beta, y, pooled, eps):
     """bn_relu and the 2x2 max-pool after it in one pass: y (like z; None = not written) and
     pooled [B,H/2,W/2,C]."""

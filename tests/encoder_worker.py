@@ -36,7 +36,8 @@ def fullsize(out):
     torch.cuda.synchronize()
     rec = {"loss": model.loss.cpu().numpy(), "output": model.network_output.cpu().numpy()}
     for i, a in enumerate(model._act):
-        z = a["z"].reshape(-1)
+        # (the first layer keeps no z by default: its normalised output stands for it)
+        z = (a["y"] if i == 0 else a["z"]).reshape(-1)
         idx = torch.from_numpy(sample_idx(z.numel(), 8192, 100 + i)).to(dev)
         rec["z_" + a["name"]] = z[idx].float().cpu().numpy()
     for name, gr in model.grads.items():

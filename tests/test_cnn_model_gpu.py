@@ -50,8 +50,10 @@ def test_forward_layer_by_layer(small_model):
     from slam_amd.network.cnn_model import CONV_LAYERS
     model, x, gt, Wl = small_model
     model.keep_full_y = True     # pooled layers write their full-resolution output only on request
+    model.first_layer_recompute = False     # ... and the first layer its z
     model.forward()
     model.keep_full_y = False
+    model.first_layer_recompute = True
     torch.cuda.synchronize()
     P = {k: v.detach().cpu() for k, v in model.params.items()}
 

@@ -478,3 +478,40 @@ def test_first_layer_backward_fused(ops, B, H, W):
     torch.cuda.synchronize()
     np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(dw.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-4, atol=1e-4 * float(dw_ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W", [(2, 10, 12), (3, 32, 32), (1, 7, 9), (4, 64, 64)])
+def test_first_layer_without_stored_z(ops, B, H, W):
+    """The first layer's forward that writes y alone, and its backward that recomputes z from the input, against
+    the calls that go through a stored z (cnn_model.py:100-113): y bit for bit (same statistics), sums, red and the
+    filter gradient up to the order of their float sums."""
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    dev = "cuda"
+    x = torch.randn(B, H, W, 4, generator=g).to(dev).to(torch.bfloat16)
+    w = (0.5 * torch.randn(3, 3, 4, 64, generator=g)).to(dev)
+    dy = torch.randn(B, H, W, 64, generator=g).to(dev).to(torch.bfloat16)
+    gamma = (1.0 + 0.1 * torch.randn(64, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(64, generator=g)).to(dev)
+    ws = torch.empty(max(ops.conv_stats_workspace_bytes(B * H * W, 64), 1 << 20) // 4, device=dev)
+    # through z
+    z = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=dev)
+    sums_ref = torch.empty(2, 64, device=dev)
+    ops.conv3x3_small_stats(x, w, z, sums_ref, ws)
+    # without z
+    y = torch.full((B, H, W, 64), 7.0, dtype=torch.bfloat16, device=dev)
+    sums = torch.full((2, 64), 7.0, device=dev)
+    ops.conv3x3_c4_bn_relu(x, w, gamma, beta, y, sums, ws, 1e-3)
+    y_ref = torch.empty_like(y)
+    ops.bn_relu(z, sums, gamma, beta, y_ref, 1e-3)          # the same statistics: the same y
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(sums.cpu().numpy(), sums_ref.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    assert torch.equal(y.cpu(), y_ref.cpu())
+    red_ref, red = torch.empty(2, 64, device=dev), torch.full((2, 64), 7.0, device=dev)
+    dw_ref, dw = torch.empty(3, 3, 4, 64, device=dev), torch.full((3, 3, 4, 64), 7.0, device=dev)
+    ops.bn_relu_bwd_first_layer(dy, z, sums, gamma, beta, red_ref, x, dw_ref, 1e-3)
+    ops.bn_relu_bwd_first_layer_recompute(dy, x, w, sums, gamma, beta, red, dw, ws, 1e-3)
+    torch.cuda.synchronize()
+    scale = float(red_ref.abs().max())
+    np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
+    np.testing.assert_allclose(dw.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(dw_ref.abs().max()))
