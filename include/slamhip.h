@@ -49,6 +49,21 @@ extern "C" {
 const char* slamhip_last_error(void);
 int slamhip_version(void);
 
+/* How partial sums meet in the encoder entry points (channel statistics, batch-norm backward sums, filter-gradient
+ * slices, split-K products; the reference's TensorFlow kernels, slam/network/cnn_model.py:100-113,146-160, give no
+ * order either).  Default: float atomics into a cleared output - the last bits differ between runs.  With
+ * SLAMHIP_DETERMINISTIC=1 in the environment (read once per process; 1 is returned here) every part is stored to its
+ * own slot of a scratch buffer and the slots are added in index order: identical bits on identical inputs.  That
+ * scratch buffer is the only device memory the library allocates (grow-only, one per device, outside stream
+ * capture; calls of this mode on different streams of one device would race on it). */
+int slamhip_deterministic(void);
+/* Zero fill by a kernel on `stream`, any address and size (never a memset node in a captured graph). */
+int slamhip_zero_fill(void* ptr, size_t bytes, void* stream);
+/* on != 0: the calling thread promises that it clears the accumulators of the encoder entry points itself (sums2c,
+ * red2c, dw, dbias: e.g. one slamhip_zero_fill over a gradient arena per training step), and the entry points skip
+ * their own clearing launches until it is switched off again.  Returns the previous setting. */
+int slamhip_caller_clears_accumulators(int on);
+
 /* ---- host: pose / label maths (float64, reference quirks kept) ------------ */
 
 /* slam/preprocess/test_import.py:18-47 - [tx ty tz qx qy qz qw] (float32 rows, as
@@ -316,6 +331,12 @@ int slamhip_transpose_cast_bf16(const float* src_rc, void* dst_cr, int R, int C,
 int slamhip_transpose_bf16(const void* src_rc, void* dst_cr, int R, int C, void* stream);
 int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad, int Cin, int Cout,
                                 void* stream);
+/* The same for n_layers <= 16 filters that lie in one flat float32 buffer (layer l at flat_params + offsets[l]), in
+ * one launch: what a training step needs after every parameter update.  offsets, cin, cout, w_fwd, w_dgrad are HOST
+ * arrays of n_layers entries; a null w_fwd[l] or w_dgrad[l] skips that layout. */
+int slamhip_conv_weight_layouts_multi(const float* flat_params, int n_layers, const long long* offsets,
+                                      const int* cin, const int* cout, void* const* w_fwd, void* const* w_dgrad,
+                                      void* stream);
 
 /* cnn_model.py:139-140 - loss[0] = tf.nn.l2_loss((out - gt) . loss_weight) =
  * 0.5 * sum of squares; d_out (may be NULL) = its gradient with respect to out.

@@ -24,6 +24,9 @@ _K4 = ctypes.c_double * 4
 SIGNATURES = {
     "slamhip_last_error": ([], ctypes.c_char_p),
     "slamhip_version": ([], _c_int),
+    "slamhip_deterministic": ([], _c_int),
+    "slamhip_zero_fill": ([_c_void_p, ctypes.c_size_t, _c_void_p], _c_int),
+    "slamhip_caller_clears_accumulators": ([_c_int], _c_int),
     "slamhip_quat_to_transformation": ([_c_void_p, _c_int, _c_void_p], _c_int),
     "slamhip_inverse_trans": ([_c_void_p, _c_int, _c_void_p], _c_int),
     "slamhip_absolute_position": ([_c_void_p, _c_int, _c_void_p], _c_int),
@@ -79,6 +82,7 @@ SIGNATURES = {
     "slamhip_transpose_cast_bf16": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_transpose_bf16": ([_c_void_p, _c_void_p, _c_int, _c_int, _c_void_p], _c_int),
     "slamhip_conv_weight_layouts": ([_c_void_p] * 3 + [_c_int] * 2 + [_c_void_p], _c_int),
+    "slamhip_conv_weight_layouts_multi": ([_c_void_p, _c_int] + [_c_void_p] * 6, _c_int),
     "slamhip_l2loss": ([_c_void_p] * 5 + [_c_int] * 2 + [_c_void_p], _c_int),
     "slamhip_weighted_sq_loss": ([_c_void_p] * 3 + [ctypes.c_float] + [_c_void_p] * 2 + [_c_int] * 2 + [_c_void_p], _c_int),
     "slamhip_posenet_loss": ([_c_void_p] * 2 + [ctypes.c_float] + [_c_void_p] * 2 + [_c_int, _c_void_p], _c_int),

@@ -16,8 +16,10 @@
 
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 
 #include "common.h"
+#include "zero_fill.h"
 
 namespace slamhip {
 
@@ -29,27 +31,71 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int LDS_PITCH = 72;   // 64 bf16 of payload + 8 of padding per row (144 B)
 
-// Zero fill as an ordinary kernel (16-byte stores, the last bytes two at a time).  The accumulators that the
-// kernels below add into with atomics are cleared with this instead of hipMemsetAsync: inside a captured
-// HIP graph a memset becomes a node of its own kind, and a replayed training step (some fifty of them)
-// gave wrong sums now and then, while the same step made of kernel nodes alone replays correctly.
-__global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p, size_t n16, uint16_t* __restrict__ tail, int ntail) {
-  const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) p[i] = make_uint4(0u, 0u, 0u, 0u);
-  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+// ---------------------------------------------------------------------------
+// How partial results meet.  By default the kernels that split a sum over workgroups (channel statistics, the
+// batch-norm backward sums, filter-gradient slices, split-K products) add their parts with float atomics into a
+// cleared output: fast, and the order of the additions - hence the last bits of the sums - differs from run to run.
+// SLAMHIP_DETERMINISTIC=1 (read once per process) selects fixed-order sums instead: every part is stored to its own
+// slot of a scratch buffer and ordered_sum_kernel adds the slots in index order, so two runs on the same inputs give
+// the same bits.  The scratch buffer is the one piece of device memory the library owns: one grow-only allocation
+// per device, made outside stream capture, shared by consecutive calls on one stream (calls of this mode on
+// different streams of one device would race on it).
+// ---------------------------------------------------------------------------
+static bool deterministic_mode() {
+  static const bool on = [] { const char* e = getenv("SLAMHIP_DETERMINISTIC"); return e && atoi(e) != 0; }();
+  return on;
 }
 
-static hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
-  if (bytes == 0) return hipSuccess;
-  if ((reinterpret_cast<uintptr_t>(ptr) & 15) || (bytes & 1)) return hipMemsetAsync(ptr, 0, bytes, s);
-  const size_t n16 = bytes / 16;
-  const int ntail = (int)((bytes % 16) / 2);
-  size_t blocks = (n16 + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)ptr, n16,
-                     (uint16_t*)((char*)ptr + n16 * 16), ntail);
+static float* det_scratch(size_t bytes) {
+  static std::mutex mu;
+  static void* buf[64] = {};
+  static size_t cap[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (cap[dev] < bytes) {
+    if (buf[dev]) (void)hipFree(buf[dev]);     // waits for the device: no kernel still reads the old buffer
+    buf[dev] = nullptr;
+    cap[dev] = 0;
+    const size_t want = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+    if (hipMalloc(&buf[dev], want) != hipSuccess) return nullptr;
+    cap[dev] = want;
+  }
+  return (float*)buf[dev];
+}
+
+// out[i] = ((part[0][i] + part[1][i]) + part[2][i]) + ... over the S slots, in that order
+__global__ void __launch_bounds__(256)
+ordered_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int S, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float acc = 0.f;
+  int sl = 0;
+  for (; sl + 7 < S; sl += 8) {        // eight loads in flight, added in slot order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(long long)(sl + j) * n + i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc += v[j];
+  }
+  for (; sl < S; ++sl) acc += part[(long long)sl * n + i];
+  out[i] = acc;
+}
+
+static hipError_t ordered_sum(const float* part, float* out, long long S, long long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ordered_sum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, part, out, (int)S, n);
   return hipGetLastError();
+}
+
+// A caller that runs many of these entry points in a row (a training step) clears all their accumulators - the
+// statistics, the batch-norm backward sums, the filter gradients - with one launch of its own and says so per
+// thread (slamhip_caller_clears_accumulators): the entry points then skip their own clearing launches.
+static thread_local int t_caller_clears = 0;
+
+static hipError_t clear_accumulator(void* ptr, size_t bytes, hipStream_t s) {
+  if (t_caller_clears || deterministic_mode()) return hipSuccess;     // cleared by the caller / overwritten by ordered_sum
+  return zero_async(ptr, bytes, s);
 }
 
 // Per-column sum and sum of squares of one wave's 32-column slice of an output tile, from the
@@ -720,7 +766,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const bf16* tile, int k0, int mbase, i
 template <int TAPS, int TM, int TN>
 __global__ void __launch_bounds__(256)
 wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P, int Cin,
-                  int Cout, int H, int W, int splitk, int total_work) {
+                  int Cout, int H, int W, int splitk, int total_work, long long det_stride) {
   // row pitch = payload + 64 bytes: the 4 rows x 2 column halves that 32 lanes of a
   // transposing read touch then fall into 8 distinct 32-byte bank groups
   constexpr int PX = TM + 32, PY = TN + 32;
@@ -840,6 +886,7 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
         const int co = co0 + wn * (TN / 2) + j * 32 + (lane & 31);
         float* dst = &dW[((long long)tap * Cin + ci) * Cout + co];
         if (splitk == 1) *dst = acc[i][j][r];   // the only contribution: plain store, dW needs no zero-fill
+        else if (det_stride) dst[slice * det_stride] = acc[i][j][r];   // fixed-order mode: this slice's own slot
         else atomicAdd(dst, acc[i][j][r]);
       }
 }
@@ -857,7 +904,7 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 wgrad_rows64_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int B, int H,
-                    int W, int Cin, int Cout, int splitk, int total_work) {
+                    int W, int Cin, int Cout, int splitk, int total_work, long long det_stride) {
   constexpr int SEG = 112, PX = 64 + 32, PY = 64 + 32;
   __shared__ __attribute__((aligned(16))) bf16 Xs[(SEG + 2) * PX];
   __shared__ __attribute__((aligned(16))) bf16 Ys[SEG * PY];
@@ -948,7 +995,9 @@ wgrad_rows64_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, flo
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       const int co = co0 + wn * 32 + (lane & 31);
-      atomicAdd(&dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co], acc[t][r]);
+      float* dst = &dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co];
+      if (det_stride) dst[slice * det_stride] = acc[t][r];   // fixed-order mode: this slice's own slot
+      else atomicAdd(dst, acc[t][r]);
     }
 }
 
@@ -964,7 +1013,7 @@ wgrad_rows64_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, flo
 template <int TM>
 __global__ void __launch_bounds__(256)
 wgrad_rowgroup_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int BH, int H,
-                      int W, int Cin, int Cout, int G, int splitk, int total_work) {
+                      int W, int Cin, int Cout, int G, int splitk, int total_work, long long det_stride) {
   constexpr int KS = 128, PX = TM + 32, PY = 64 + 32, MT = TM / 64;
   constexpr int XT = TM / 16;                    // threads per X row (16 channels each)
   constexpr int XR = 256 / XT;                   // X rows per loader pass
@@ -1087,7 +1136,9 @@ wgrad_rowgroup_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, f
       for (int r = 0; r < 16; ++r) {
         const int ci = ci0 + wm * (TM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int co = co0 + wn * 32 + (lane & 31);
-        atomicAdd(&dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co], acc[t][i][r]);
+        float* dst = &dW[((long long)(dyi * 3 + t) * Cin + ci) * Cout + co];
+        if (det_stride) dst[slice * det_stride] = acc[t][i][r];   // fixed-order mode: this slice's own slot
+        else atomicAdd(dst, acc[t][i][r]);
       }
 }
 
@@ -1114,7 +1165,7 @@ conv3x3_small_fwd_kernel(const bf16* __restrict__ X, const float* __restrict__ W
 
 __global__ void __launch_bounds__(256)
 conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P,
-                           int H, int W, int Cin, int Cout) {
+                           int H, int W, int Cin, int Cout, long long det_stride) {
   // one block per (tap, ci); thread = co; loops over a slice of the pixels
   const int t = blockIdx.x / Cin, ci = blockIdx.x % Cin;
   const int co = threadIdx.x % Cout, lanes_per_co = blockDim.x / Cout, sub = threadIdx.x / Cout;
@@ -1128,7 +1179,8 @@ conv3x3_small_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__ 
     if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
     acc = __builtin_fmaf((float)X[((long long)(b * H + yy) * W + xx) * Cin + ci], (float)dY[(long long)p * Cout + co], acc);
   }
-  atomicAdd(&dW[(t * Cin + ci) * Cout + co], acc);
+  if (det_stride) dW[slice * det_stride + (t * Cin + ci) * Cout + co] = acc;   // fixed-order mode: one slot per slice
+  else atomicAdd(&dW[(t * Cin + ci) * Cout + co], acc);
 }
 
 // Specialisation for the network's actual first layer (4 input channels, 64 filters) on the
@@ -1267,7 +1319,7 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
                             int H, int W, int px_per_block, const bf16* __restrict__ Z,
                             const float* __restrict__ sums, const float* __restrict__ red,
                             const float* __restrict__ gamma, const float* __restrict__ beta, float inv_count,
-                            float eps) {
+                            float eps, long long det_stride) {
   constexpr int PX = 64 + 32;   // conflict-free pitch of the transposing reads (see wgrad_bf16_kernel)
   __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];
   __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PX];
@@ -1368,7 +1420,11 @@ conv3x3_c4_k64_wgrad_kernel(const bf16* __restrict__ X, const bf16* __restrict__
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int k = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (k < 36) atomicAdd(&dW[k * 64 + wn * 32 + (lane & 31)], acc[r]);
+    if (k < 36) {
+      float* dst = &dW[k * 64 + wn * 32 + (lane & 31)];
+      if (det_stride) dst[blockIdx.x * det_stride] = acc[r];   // fixed-order mode: one slot per workgroup
+      else atomicAdd(dst, acc[r]);
+    }
   }
 }
 
@@ -1388,7 +1444,7 @@ conv3x3_c4_k64_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ d
                           float* __restrict__ dW, float* __restrict__ red_part, int P, int H, int W,
                           int px_per_block, const float* __restrict__ sums, const float* __restrict__ red,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float inv_count,
-                          float eps) {
+                          float eps, long long det_stride) {
   constexpr int PX = 64 + 32;   // conflict-free pitch of the transposing reads (see wgrad_bf16_kernel)
   __shared__ __attribute__((aligned(16))) bf16 Xs[64 * PX];          // im2col rows [pixel][k]
   __shared__ __attribute__((aligned(16))) bf16 Ys[64 * PX];          // dy, then dz [pixel][channel]
@@ -1500,7 +1556,11 @@ conv3x3_c4_k64_bwd_kernel(const bf16* __restrict__ X, const bf16* __restrict__ d
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int k = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (k < 36) atomicAdd(&dW[k * 64 + wn * 32 + (lane & 31)], acc[r]);
+      if (k < 36) {
+        float* dst = &dW[k * 64 + wn * 32 + (lane & 31)];
+        if (det_stride) dst[blockIdx.x * det_stride] = acc[r];   // fixed-order mode: one slot per workgroup
+        else atomicAdd(dst, acc[r]);
+      }
     }
   } else {
     // lanes l and l + 32 hold the same channel; the two pixel halves (waves wm = 0, 1) meet in LDS, in a fixed order
@@ -1534,7 +1594,7 @@ __global__ void __launch_bounds__(256)
 channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, const bf16* __restrict__ z,
                       const float* __restrict__ sums, const float* __restrict__ gamma,
                       const float* __restrict__ beta, float* __restrict__ out, int P, int C, float inv_count,
-                      float eps) {
+                      float eps, int det) {
   __shared__ float part[256 * 17];
   const int groups = C >> 3;                      // <= 256 (checked on the host)
   const int rlanes = 256 / groups;
@@ -1590,14 +1650,16 @@ channel_reduce_kernel(const bf16* __restrict__ a, const bf16* __restrict__ y, co
     if (BWD == 2 && k >= 8) continue;
     float acc = 0.f;
     for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
-    atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
+    float* dst = &out[(k >> 3) * C + gc * 8 + (k & 7)];
+    if (det) dst[(long long)blockIdx.x * (BWD == 2 ? C : 2 * C)] = acc;   // fixed-order mode: one slot per workgroup
+    else atomicAdd(dst, acc);
   }
 }
 
 // second stage of the statistics that the convolution kernels leave per tile:
 // sums[c] += sum over the R records of part[r][c], c in [0, 2N)
 __global__ void __launch_bounds__(256)
-stat_finish_kernel(const float* __restrict__ part, float* __restrict__ sums, int R, int N2) {
+stat_finish_kernel(const float* __restrict__ part, float* __restrict__ sums, int R, int N2, int det) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= N2) return;
   const int chunk = (R + gridDim.y - 1) / gridDim.y, r0 = blockIdx.y * chunk, r1 = min(R, r0 + chunk);
@@ -1612,7 +1674,9 @@ stat_finish_kernel(const float* __restrict__ part, float* __restrict__ sums, int
     for (int j = 0; j < 8; ++j) a[j] += v[j];
   }
   for (; r < r1; ++r) a[0] += part[(long long)r * N2 + c];
-  if (r0 < r1) atomicAdd(&sums[c], ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7])));
+  const float t = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  if (det) sums[(long long)blockIdx.y * N2 + c] = t;     // fixed-order mode: one slot per slice of the records (zero if empty)
+  else if (r0 < r1) atomicAdd(&sums[c], t);
 }
 
 // Both element-wise batch-norm kernels walk the tensor with a stride that is a multiple of C
@@ -1862,7 +1926,7 @@ bn_relu_pool_fwd_kernel(const bf16* __restrict__ z, const float* __restrict__ su
 __global__ void __launch_bounds__(256)
 bn_pool_bwd_reduce_kernel(const bf16* __restrict__ dpooled, const bf16* __restrict__ z, const float* __restrict__ sums,
                           const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ out,
-                          long long PP, int H, int W, int C, float inv_count, float eps) {
+                          long long PP, int H, int W, int C, float inv_count, float eps, int det) {
   __shared__ float part[256 * 17];
   const int groups = C >> 3;
   const int rlanes = 256 / groups;
@@ -1908,7 +1972,9 @@ bn_pool_bwd_reduce_kernel(const bf16* __restrict__ dpooled, const bf16* __restri
     const int gc = t >> 4, k = t & 15;
     float acc = 0.f;
     for (int r = 0; r < rlanes; ++r) acc += part[(r * groups + gc) * 17 + k];
-    atomicAdd(&out[(k >> 3) * C + gc * 8 + (k & 7)], acc);
+    float* dst = &out[(k >> 3) * C + gc * 8 + (k & 7)];
+    if (det) dst[(long long)blockIdx.x * 2 * C] = acc;   // fixed-order mode: one slot per workgroup
+    else atomicAdd(dst, acc);
   }
 }
 
@@ -1966,6 +2032,18 @@ __global__ void __launch_bounds__(256)
 cast_f32_bf16_kernel(const float* __restrict__ src, bf16* __restrict__ dst, long long n) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = (bf16)src[i];
+}
+
+// eight elements per thread: two 16-byte loads, one 16-byte store (both bases 16-byte aligned, n8 = n / 8)
+__global__ void __launch_bounds__(256)
+cast_f32_bf16_x8_kernel(const float4* __restrict__ src, bf16x8* __restrict__ dst, long long n8) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n8) return;
+  const float4 a = src[2 * i], b = src[2 * i + 1];
+  bf16x8 o;
+  o[0] = (bf16)a.x; o[1] = (bf16)a.y; o[2] = (bf16)a.z; o[3] = (bf16)a.w;
+  o[4] = (bf16)b.x; o[5] = (bf16)b.y; o[6] = (bf16)b.z; o[7] = (bf16)b.w;
+  dst[i] = o;
 }
 
 // dst[c][r] = bf16(src[r][c]) for a row-major [R][Ccols] float matrix (32x32 LDS tiles)
@@ -2027,6 +2105,32 @@ conv_weight_layouts_kernel(const float* __restrict__ w, bf16* __restrict__ w_fwd
   const bf16 v = (bf16)w[i];
   if (w_fwd) w_fwd[(long long)co * 9 * Cin + t * Cin + ci] = v;
   if (w_dgrad) w_dgrad[(long long)ci * 9 * Cout + t * Cout + co] = v;
+}
+
+// The same re-layout for up to 16 layers whose filters lie in one flat parameter buffer: one launch per training
+// step instead of one per layer.
+struct ConvLayoutTable {
+  long long src[16];      // offset of the layer's [9][Cin][Cout] filter in the flat buffer (floats)
+  long long end[16];      // running total of filter elements up to and including the layer
+  bf16* w_fwd[16];
+  bf16* w_dgrad[16];
+  int cin[16], cout[16];
+  int n;
+};
+__global__ void __launch_bounds__(256)
+conv_weight_layouts_multi_kernel(const float* __restrict__ flat, ConvLayoutTable t) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= t.end[t.n - 1]) return;
+  int l = 0;
+  while (g >= t.end[l]) ++l;
+  const long long i = g - (l ? t.end[l - 1] : 0);
+  const int Cin = t.cin[l], Cout = t.cout[l];
+  const int co = (int)(i % Cout);
+  const int ci = (int)((i / Cout) % Cin);
+  const int tap = (int)(i / ((long long)Cout * Cin));
+  const bf16 v = (bf16)flat[t.src[l] + i];
+  if (t.w_fwd[l]) t.w_fwd[l][(long long)co * 9 * Cin + tap * Cin + ci] = v;
+  if (t.w_dgrad[l]) t.w_dgrad[l][(long long)ci * 9 * Cout + tap * Cout + co] = v;
 }
 
 // ---------------------------------------------------------------------------
@@ -2237,6 +2341,25 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
   return (M + 127) / 128 * 2;
 }
 
+// Runs launch(dst, det): a kernel whose `slots` workgroups (or slices) each contribute `width` floats to `out` - with
+// atomics into the cleared `out` (det = 0, dst = out), or each to its own slot of the scratch buffer, added
+// afterwards in slot order (det = 1; every slot must be written).
+template <typename F>
+static int accumulate(float* out, long long width, long long slots, hipStream_t s, F launch) {
+  if (deterministic_mode()) {
+    float* part = det_scratch(sizeof(float) * (size_t)width * (size_t)slots);
+    SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+    launch(part, 1);
+    SLAMHIP_HIP(hipGetLastError());
+    SLAMHIP_HIP(ordered_sum(part, out, slots, width, s));
+    return SLAMHIP_OK;
+  }
+  SLAMHIP_HIP(clear_accumulator(out, sizeof(float) * (size_t)width, s));
+  launch(out, 0);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
 // Grid of the first layer's forward kernel, whose workgroups walk the pixel tiles: as many workgroups as the chip
 // holds at once (a grid of 2048 on 1280 slots ran a second, 60 % full round)
 template <int MODE>
@@ -2281,11 +2404,20 @@ size_t slamhip_conv_stats_workspace_bytes(long long pixels, int N) {
 
 // sums2c[0..2N) = column sums of the R per-tile records in ws
 static int finish_stats(const float* ws, float* sums2c, long long R, int N, hipStream_t s) {
-  SLAMHIP_HIP(zero_async(sums2c, sizeof(float) * 2 * (size_t)N, s));
   long long slices = (R + 63) / 64;
   if (slices > 512) slices = 512;
-  hipLaunchKernelGGL(stat_finish_kernel, dim3((2 * N + 255) / 256, (unsigned)slices), dim3(256), 0, s, ws, sums2c,
-                     (int)R, 2 * N);
+  if (slices < 1) slices = 1;
+  const dim3 grid((2 * N + 255) / 256, (unsigned)slices);
+  if (deterministic_mode()) {      // the slices' sums to their own slots, then added in slice order
+    float* part = det_scratch(sizeof(float) * 2 * (size_t)N * slices);
+    SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+    hipLaunchKernelGGL(stat_finish_kernel, grid, dim3(256), 0, s, ws, part, (int)R, 2 * N, 1);
+    SLAMHIP_HIP(hipGetLastError());
+    SLAMHIP_HIP(ordered_sum(part, sums2c, slices, 2LL * N, s));
+    return SLAMHIP_OK;
+  }
+  SLAMHIP_HIP(clear_accumulator(sums2c, sizeof(float) * 2 * (size_t)N, s));
+  hipLaunchKernelGGL(stat_finish_kernel, grid, dim3(256), 0, s, ws, sums2c, (int)R, 2 * N, 0);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -2319,7 +2451,7 @@ int slamhip_gemm_nt_bf16(const void* a_mk, const void* b_nk, void* out_bf16, flo
   const int bn = (N % 128 == 0) ? 128 : 64;
   const long long tiles = (long long)((M + 127) / 128) * ((N + bn - 1) / bn);
   int splitk = 1;
-  if (!out_bf16 && tiles < 256 && K >= 1024) {
+  if (!out_bf16 && tiles < 256 && K >= 1024 && !deterministic_mode()) {   // (fixed-order mode: one slice, no atomics)
     splitk = (int)((512 + tiles - 1) / tiles);
     if (splitk > K / 256) splitk = K / 256;      // at least four K-steps per slice
     if (splitk < 1) splitk = 1;
@@ -2352,11 +2484,19 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
     if (split < 1) split = 1;
     const long long chunk = (S + split - 1) / split;
     split = (S + chunk - 1) / chunk;
-    SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+    const long long n_dw = 9LL * Cin * Cout;
+    float* part = nullptr;
+    if (deterministic_mode()) {
+      part = det_scratch(sizeof(float) * (size_t)n_dw * split);
+      SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+    } else {
+      SLAMHIP_HIP(clear_accumulator(dw, sizeof(float) * (size_t)n_dw, s));
+    }
     const long long total3 = tiles3 * split;
     hipLaunchKernelGGL(wgrad_rows64_kernel, dim3((unsigned)((total3 + 7) / 8 * 8)), dim3(256), 0, s, (const bf16*)x,
-                       (const bf16*)dy, dw, B, H, W, Cin, Cout, (int)split, (int)total3);
+                       (const bf16*)dy, part ? part : dw, B, H, W, Cin, Cout, (int)split, (int)total3, part ? n_dw : 0LL);
     SLAMHIP_HIP(hipGetLastError());
+    if (part) SLAMHIP_HIP(ordered_sum(part, dw, split, n_dw, s));
     return SLAMHIP_OK;
   }
   // narrow images (56, 28, 14 wide here): groups of whole image rows per K-step, see the kernel.
@@ -2374,16 +2514,26 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
       if (split < 1) split = 1;
       const long long chunk = (S + split - 1) / split;
       split = (S + chunk - 1) / chunk;
-      SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
+      const long long n_dw = 9LL * Cin * Cout;
+      float* part = nullptr;
+      if (deterministic_mode()) {
+        part = det_scratch(sizeof(float) * (size_t)n_dw * split);
+        SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+      } else {
+        SLAMHIP_HIP(clear_accumulator(dw, sizeof(float) * (size_t)n_dw, s));
+      }
+      float* const dst = part ? part : dw;
+      const long long stride = part ? n_dw : 0LL;
       const long long total3 = tiles3 * split;
       const dim3 grid3((unsigned)((total3 + 7) / 8 * 8));
       if (TMg == 128)
-        hipLaunchKernelGGL(wgrad_rowgroup_kernel<128>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw,
-                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3);
+        hipLaunchKernelGGL(wgrad_rowgroup_kernel<128>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dst,
+                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3, stride);
       else
-        hipLaunchKernelGGL(wgrad_rowgroup_kernel<64>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dw,
-                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3);
+        hipLaunchKernelGGL(wgrad_rowgroup_kernel<64>, grid3, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, dst,
+                           (int)BH, H, W, Cin, Cout, G, (int)split, (int)total3, stride);
       SLAMHIP_HIP(hipGetLastError());
+      if (part) SLAMHIP_HIP(ordered_sum(part, dw, split, n_dw, s));
       return SLAMHIP_OK;
     }
   }
@@ -2402,14 +2552,28 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
     const long long chunk = ((P + splitk - 1) / splitk + 63) / 64 * 64;
     splitk = (P + chunk - 1) / chunk;
   }
-  if (splitk != 1 || P == 0) SLAMHIP_HIP(zero_async(dw, sizeof(float) * (size_t)taps * Cin * Cout, s));
-  if (P == 0) return SLAMHIP_OK;
+  const long long n_dw = (long long)taps * Cin * Cout;
+  if (P == 0) {
+    SLAMHIP_HIP(zero_async(dw, sizeof(float) * (size_t)n_dw, s));
+    return SLAMHIP_OK;
+  }
+  float* part = nullptr;
+  if (splitk != 1) {
+    if (deterministic_mode()) {
+      part = det_scratch(sizeof(float) * (size_t)n_dw * splitk);
+      SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+    } else {
+      SLAMHIP_HIP(clear_accumulator(dw, sizeof(float) * (size_t)n_dw, s));
+    }
+  }
+  float* const dst = part ? part : dw;
+  const long long stride = part ? n_dw : 0LL;
   const long long total = tiles * splitk;
   SLAMHIP_REQUIRE(total < (1LL << 30), SLAMHIP_E_SIZE, "wgrad: too many workgroups");
   const dim3 grid((unsigned)((total + 7) / 8 * 8));
 #define SLAMHIP_WGRAD_GO(TAPS_, TM_, TN_)                                                                          \
   hipLaunchKernelGGL((wgrad_bf16_kernel<TAPS_, TM_, TN_>), grid, dim3(256), 0, s, (const bf16*)x, (const bf16*)dy, \
-                     dw, (int)P, Cin, Cout, H, W, (int)splitk, (int)total)
+                     dst, (int)P, Cin, Cout, H, W, (int)splitk, (int)total, stride)
   if (taps == 9) {
     if (TM == 128 && TN == 128) SLAMHIP_WGRAD_GO(9, 128, 128);
     else if (TM == 64 && TN == 128) SLAMHIP_WGRAD_GO(9, 64, 128);
@@ -2423,6 +2587,7 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   }
 #undef SLAMHIP_WGRAD_GO
   SLAMHIP_HIP(hipGetLastError());
+  if (part) SLAMHIP_HIP(ordered_sum(part, dw, splitk, n_dw, s));
   return SLAMHIP_OK;
 }
 
@@ -2477,36 +2642,44 @@ int slamhip_conv3x3_small_wgrad(const void* x, const void* dy, float* dw, int B,
   SLAMHIP_REQUIRE(x && dy && dw && B >= 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && Cout <= 256 && 256 % Cout == 0,
                   SLAMHIP_E_ARG, "conv3x3_small_wgrad: bad argument (Cout must divide 256)");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * (size_t)Cin * Cout, s));
-  if (B == 0) return SLAMHIP_OK;
+  const long long n_dw = 9LL * Cin * Cout;
+  if (B == 0) {
+    SLAMHIP_HIP(zero_async(dw, sizeof(float) * (size_t)n_dw, s));
+    return SLAMHIP_OK;
+  }
   const int P = B * H * W;
   if (Cin == 4 && Cout == 64) {
     // about 2048 workgroups, slices in multiples of 64 pixels
-    int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
-    hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<false>, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0,
-                       s, (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block, (const bf16*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                       0.0f, 0.0f);
-  } else {
-    hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x,
-                       (const bf16*)dy, dw, P, H, W, Cin, Cout);
+    const int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
+    const int blocks = (P + px_per_block - 1) / px_per_block;
+    return accumulate(dw, n_dw, blocks, s, [&](float* dst, int det) {
+      hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, s, (const bf16*)x,
+                         (const bf16*)dy, dst, P, H, W, px_per_block, (const bf16*)nullptr, (const float*)nullptr,
+                         (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, 0.0f, 0.0f,
+                         det ? n_dw : 0LL);
+    });
   }
-  SLAMHIP_HIP(hipGetLastError());
-  return SLAMHIP_OK;
+  return accumulate(dw, n_dw, 64LL * (256 / Cout), s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(conv3x3_small_wgrad_kernel, dim3(9 * Cin, 64), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
+                       dst, P, H, W, Cin, Cout, det ? n_dw : 0LL);
+  });
 }
 
 int slamhip_channel_stats(const void* z, float* sums2c, long long P, int C, void* stream) {
   SLAMHIP_REQUIRE(z && sums2c && P >= 0 && C > 0 && C % 64 == 0, SLAMHIP_E_ARG, "channel_stats: bad argument");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(sums2c, sizeof(float) * 2 * (size_t)C, s));
-  if (P == 0) return SLAMHIP_OK;
+  if (P == 0) {
+    SLAMHIP_HIP(zero_async(sums2c, sizeof(float) * 2 * (size_t)C, s));
+    return SLAMHIP_OK;
+  }
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "channel_stats: too many rows");
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "channel_stats: more than 2048 channels");
-  hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)z,
-                     (const bf16*)nullptr, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, sums2c, (int)P, C, 0.0f, 0.0f);
-  SLAMHIP_HIP(hipGetLastError());
-  return SLAMHIP_OK;
+  const unsigned grid = reduce_grid(P, C);
+  return accumulate(sums2c, 2LL * C, grid, s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(channel_reduce_kernel<0>, dim3(grid), dim3(256), 0, s, (const bf16*)z, (const bf16*)nullptr,
+                       (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dst,
+                       (int)P, C, 0.0f, 0.0f, det);
+  });
 }
 
 int slamhip_bn_relu_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta, void* y,
@@ -2533,9 +2706,12 @@ int slamhip_bn_relu_bwd_phases(const void* dy, const void* z, const float* sums2
   SLAMHIP_REQUIRE(C <= 2048, SLAMHIP_E_SIZE, "bn_relu_bwd: more than 2048 channels");
   hipStream_t s = (hipStream_t)stream;
   if (phases & 1) {
-    SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
-    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                       (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, (int)P, C, 1.0f / (float)P, eps);
+    const unsigned grid = reduce_grid(P, C);
+    const int rc = accumulate(red2c, 2LL * C, grid, s, [&](float* dst, int det) {
+      hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)nullptr,
+                         (const bf16*)z, sums2c, gamma, beta, dst, (int)P, C, 1.0f / (float)P, eps, det);
+    });
+    if (rc != SLAMHIP_OK) return rc;
   }
   if (phases & 2) {
     const long long total8 = P * C / 8;
@@ -2560,16 +2736,20 @@ int slamhip_bn_relu_bwd_first_layer(const void* dy, const void* z, const float* 
   SLAMHIP_REQUIRE(Pl <= 0x7fffffffLL / 64, SLAMHIP_E_SIZE, "bn_relu_bwd_first_layer: too many pixels");
   const int P = (int)Pl, C = 64;
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
-  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * 4 * (size_t)C, s));
-  hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)nullptr, (const bf16*)z, sums2c, gamma, beta, red2c, P, C, 1.0f / (float)P, eps);
+  const unsigned grid = reduce_grid(P, C);
+  const int rc = accumulate(red2c, 2LL * C, grid, s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(channel_reduce_kernel<1>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)nullptr,
+                       (const bf16*)z, sums2c, gamma, beta, dst, P, C, 1.0f / (float)P, eps, det);
+  });
+  if (rc != SLAMHIP_OK) return rc;
   const int px_per_block = ((P + 2047) / 2048 + 63) / 64 * 64;
-  hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<true>, dim3((P + px_per_block - 1) / px_per_block), dim3(256), 0, s,
-                     (const bf16*)x, (const bf16*)dy, dw, P, H, W, px_per_block, (const bf16*)z, sums2c,
-                     (const float*)red2c, gamma, beta, 1.0f / (float)P, eps);
-  SLAMHIP_HIP(hipGetLastError());
-  return SLAMHIP_OK;
+  const int blocks = (P + px_per_block - 1) / px_per_block;
+  const long long n_dw = 9LL * 4 * C;
+  return accumulate(dw, n_dw, blocks, s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(conv3x3_c4_k64_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, s, (const bf16*)x,
+                       (const bf16*)dy, dst, P, H, W, px_per_block, (const bf16*)z, sums2c, (const float*)red2c, gamma,
+                       beta, 1.0f / (float)P, eps, det ? n_dw : 0LL);
+  });
 }
 
 int slamhip_conv3x3_c4_bn_relu_fwd(const void* x, const float* w_hwio, const float* gamma, const float* beta,
@@ -2611,18 +2791,18 @@ int slamhip_bn_relu_bwd_first_layer_recompute(const void* dy, const void* x, con
                   "bn_relu_bwd_first_layer_recompute: workspace of %zu bytes, need %zu", workspace_bytes,
                   sizeof(float) * 128 * (size_t)blocks);
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(dw, sizeof(float) * 9 * 4 * (size_t)C, s));
   hipLaunchKernelGGL(conv3x3_c4_k64_bwd_kernel<0>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
                      w_hwio, (float*)nullptr, (float*)workspace, P, H, W, px_per_block, sums2c, (const float*)nullptr,
-                     gamma, beta, 1.0f / (float)P, eps);
+                     gamma, beta, 1.0f / (float)P, eps, 0LL);
   SLAMHIP_HIP(hipGetLastError());
   const int rc = finish_stats((const float*)workspace, red2c, blocks, C, s);
   if (rc != SLAMHIP_OK) return rc;
-  hipLaunchKernelGGL(conv3x3_c4_k64_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
-                     w_hwio, dw, (float*)nullptr, P, H, W, px_per_block, sums2c, (const float*)red2c, gamma, beta,
-                     1.0f / (float)P, eps);
-  SLAMHIP_HIP(hipGetLastError());
-  return SLAMHIP_OK;
+  const long long n_dw = 9LL * 4 * C;
+  return accumulate(dw, n_dw, blocks, s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(conv3x3_c4_k64_bwd_kernel<1>, dim3(blocks), dim3(256), 0, s, (const bf16*)x, (const bf16*)dy,
+                       w_hwio, dst, (float*)nullptr, P, H, W, px_per_block, sums2c, (const float*)red2c, gamma, beta,
+                       1.0f / (float)P, eps, det ? n_dw : 0LL);
+  });
 }
 
 int slamhip_bn_relu_pool_fwd(const void* z, const float* sums2c, const float* gamma, const float* beta, void* y,
@@ -2648,9 +2828,12 @@ int slamhip_bn_relu_pool_bwd_phases(const void* dpooled, const void* z, const fl
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bn_relu_pool_bwd: too many pixels");
   hipStream_t s = (hipStream_t)stream;
   if (phases & 1) {
-    SLAMHIP_HIP(zero_async(red2c, sizeof(float) * 2 * (size_t)C, s));
-    hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(reduce_grid(PP, C)), dim3(256), 0, s, (const bf16*)dpooled,
-                       (const bf16*)z, sums2c, gamma, beta, red2c, PP, H, W, C, 1.0f / (float)P, eps);
+    const unsigned grid = reduce_grid(PP, C);
+    const int rc = accumulate(red2c, 2LL * C, grid, s, [&](float* dst, int det) {
+      hipLaunchKernelGGL(bn_pool_bwd_reduce_kernel, dim3(grid), dim3(256), 0, s, (const bf16*)dpooled, (const bf16*)z,
+                         sums2c, gamma, beta, dst, PP, H, W, C, 1.0f / (float)P, eps, det);
+    });
+    if (rc != SLAMHIP_OK) return rc;
   }
   if (phases & 2) {
     const long long total8 = PP * (C / 8);
@@ -2716,7 +2899,14 @@ int slamhip_maxpool2_bwd(const void* x, const void* y, const void* dy, void* dx,
 int slamhip_cast_f32_bf16(const float* src, void* dst, long long n, void* stream) {
   SLAMHIP_REQUIRE(src && dst && n >= 0, SLAMHIP_E_ARG, "cast_f32_bf16: bad argument");
   if (n == 0) return SLAMHIP_OK;
-  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for(n)), dim3(256), 0, (hipStream_t)stream, src, (bf16*)dst, n);
+  long long n8 = 0;
+  if (reinterpret_cast<uintptr_t>(src) % 16 == 0 && reinterpret_cast<uintptr_t>(dst) % 16 == 0) n8 = n / 8;
+  if (n8)
+    hipLaunchKernelGGL(cast_f32_bf16_x8_kernel, dim3(blocks_for(n8)), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)src, (bf16x8*)dst, n8);
+  if (n - 8 * n8)
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks_for(n - 8 * n8)), dim3(256), 0, (hipStream_t)stream,
+                       src + 8 * n8, (bf16*)dst + 8 * n8, n - 8 * n8);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -2747,6 +2937,33 @@ int slamhip_conv_weight_layouts(const float* w_hwio, void* w_fwd, void* w_dgrad,
   SLAMHIP_REQUIRE(w_hwio && (w_fwd || w_dgrad) && Cin > 0 && Cout > 0, SLAMHIP_E_ARG, "conv_weight_layouts: bad argument");
   hipLaunchKernelGGL(conv_weight_layouts_kernel, dim3(blocks_for(9LL * Cin * Cout)), dim3(256), 0,
                      (hipStream_t)stream, w_hwio, (bf16*)w_fwd, (bf16*)w_dgrad, Cin, Cout);
+  SLAMHIP_HIP(hipGetLastError());
+  return SLAMHIP_OK;
+}
+
+int slamhip_conv_weight_layouts_multi(const float* flat_params, int n_layers, const long long* offsets,
+                                      const int* cin, const int* cout, void* const* w_fwd, void* const* w_dgrad,
+                                      void* stream) {
+  SLAMHIP_REQUIRE(flat_params && offsets && cin && cout && w_fwd && w_dgrad && n_layers >= 0 && n_layers <= 16,
+                  SLAMHIP_E_ARG, "conv_weight_layouts_multi: bad argument (at most 16 layers)");
+  if (n_layers == 0) return SLAMHIP_OK;
+  ConvLayoutTable t;
+  long long total = 0;
+  for (int l = 0; l < 16; ++l) {
+    const bool live = l < n_layers;
+    SLAMHIP_REQUIRE(!live || (offsets[l] >= 0 && cin[l] > 0 && cout[l] > 0 && (w_fwd[l] || w_dgrad[l])), SLAMHIP_E_ARG,
+                    "conv_weight_layouts_multi: bad layer %d", l);
+    if (live) total += 9LL * cin[l] * cout[l];
+    t.src[l] = live ? offsets[l] : 0;
+    t.end[l] = total;
+    t.w_fwd[l] = live ? (bf16*)w_fwd[l] : nullptr;
+    t.w_dgrad[l] = live ? (bf16*)w_dgrad[l] : nullptr;
+    t.cin[l] = live ? cin[l] : 1;
+    t.cout[l] = live ? cout[l] : 1;
+  }
+  t.n = n_layers;
+  hipLaunchKernelGGL(conv_weight_layouts_multi_kernel, dim3(blocks_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     flat_params, t);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
@@ -2789,11 +3006,17 @@ int slamhip_bias_relu_bwd(const void* dy, const void* y, void* dz, float* dbias,
                   "bias_relu_bwd: bad argument");
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "bias_relu_bwd: too many rows");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(zero_async(dbias, sizeof(float) * (size_t)C, s));
-  if (P == 0) return SLAMHIP_OK;
-  hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(reduce_grid(P, C)), dim3(256), 0, s, (const bf16*)dy,
-                     (const bf16*)y, (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, dbias, (int)P, C, 0.0f, 0.0f);
+  if (P == 0) {
+    SLAMHIP_HIP(zero_async(dbias, sizeof(float) * (size_t)C, s));
+    return SLAMHIP_OK;
+  }
+  const unsigned grid = reduce_grid(P, C);
+  const int rc = accumulate(dbias, C, grid, s, [&](float* dst, int det) {
+    hipLaunchKernelGGL(channel_reduce_kernel<2>, dim3(grid), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
+                       (const bf16*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dst,
+                       (int)P, C, 0.0f, 0.0f, det);
+  });
+  if (rc != SLAMHIP_OK) return rc;
   const long long total8 = P * C / 8;
   hipLaunchKernelGGL(relu_gate_kernel, dim3(blocks_for(total8)), dim3(256), 0, s, (const bf16*)dy, (const bf16*)y,
                      (bf16*)dz, total8);
@@ -2856,5 +3079,19 @@ int slamhip_rmsprop_step(float* param, const float* grad, float* ms, long long n
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
 }
+
+int slamhip_zero_fill(void* ptr, size_t bytes, void* stream) {
+  SLAMHIP_REQUIRE(ptr || bytes == 0, SLAMHIP_E_ARG, "zero_fill: null pointer");
+  SLAMHIP_HIP(zero_async(ptr, bytes, (hipStream_t)stream));
+  return SLAMHIP_OK;
+}
+
+int slamhip_caller_clears_accumulators(int on) {
+  const int before = t_caller_clears;
+  t_caller_clears = on ? 1 : 0;
+  return before;
+}
+
+int slamhip_deterministic(void) { return deterministic_mode() ? 1 : 0; }
 
 }  // extern "C"

@@ -21,6 +21,7 @@
 #include <cstdint>
 
 #include "common.h"
+#include "zero_fill.h"
 
 namespace slamhip {
 
@@ -349,7 +350,7 @@ int slamhip_bias_act_slice_bwd(const void* dy_bf16, const float* dy_f32, const v
   SLAMHIP_REQUIRE(dbias && (M == 0 || ((dy_bf16 || dy_f32) && dz && (y_bf16 || !relu))), SLAMHIP_E_ARG,
                   "bias_act_slice_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  SLAMHIP_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * (size_t)Np, s));
+  SLAMHIP_HIP(zero_async(dbias, sizeof(float) * (size_t)Np, s));
   if (M == 0) return SLAMHIP_OK;
   long long slices = (M + 1023) / 1024;
   if (slices > 1024) slices = 1024;

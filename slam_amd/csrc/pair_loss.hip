@@ -24,6 +24,7 @@
 #include <string>
 
 #include "geom_device.h"
+#include "zero_fill.h"
 
 namespace slamhip {
 
@@ -891,21 +892,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
 static bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Clears accumulator records with a kernel (a record is 128 bytes, eight 16-byte stores): callers may record
-// these entry points in a HIP graph, where a memset becomes a node of its own kind; kernel nodes alone
-// replay in order.
-__global__ void __launch_bounds__(256) clear_records_kernel(uint4* __restrict__ p, size_t n16) {
-  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-
-static hipError_t clear_records(void* workspace, size_t bytes, hipStream_t s) {
-  if (bytes == 0) return hipSuccess;
-  if (!aligned_to(workspace, 16) || bytes % 16) return hipMemsetAsync(workspace, 0, bytes, s);
-  const size_t n16 = bytes / 16;
-  hipLaunchKernelGGL(clear_records_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, s, (uint4*)workspace, n16);
-  return hipGetLastError();
-}
+// Accumulator records are cleared with a kernel (zero_fill.h), never with a memset: callers may record these entry
+// points in a HIP graph, where a memset becomes a node of its own kind; kernel nodes alone replay in order.
+static hipError_t clear_records(void* workspace, size_t bytes, hipStream_t s) { return zero_async(workspace, bytes, s); }
 
 }  // namespace slamhip
 

@@ -216,10 +216,14 @@ class VGG16Model:
         self._x = torch.empty(B, H, W, cin, **bf)
         self._act = []     # per conv layer: dict(z, y, pooled, sums)
         h, w = H, W
+        # the channel statistics of all layers lie in one buffer, cleared by one launch per forward pass
+        self._sums_arena = torch.zeros(sum(2 * co for _, _, co in conv_shapes), **f32)
+        sums_off = 0
         for (name, ci, co), (_, _, pool) in zip(conv_shapes, CONV_LAYERS):
             a = dict(name=name, cin=ci, cout=co, pool=pool,
                      z=torch.empty(B, h, w, co, **bf), y=torch.empty(B, h, w, co, **bf),
-                     sums=torch.empty(2, co, **f32))
+                     sums=self._sums_arena[sums_off:sums_off + 2 * co].view(2, co))
+            sums_off += 2 * co
             if pool:
                 h, w = h // 2, w // 2
                 a["pooled"] = torch.empty(B, h, w, co, **bf)
@@ -241,6 +245,12 @@ class VGG16Model:
         # 4-channel input (SLAM_FIRST_RECOMPUTE=0: z is written and read as in every other layer)
         self.first_layer_recompute = (os.environ.get("SLAM_FIRST_RECOMPUTE", "1") not in ("", "0")
                                       and self.batch_norm and cin == 4 and not CONV_LAYERS[0][2])
+        # one clearing launch per pass for all the accumulators the kernels add into (channel statistics in the
+        # forward pass; filter gradients and batch-norm sums, i.e. the convolution part of flat_grads, in the
+        # backward pass) instead of one per entry point (SLAM_MERGE_CLEARS=0: every entry point clears its own)
+        self.merge_clears = os.environ.get("SLAM_MERGE_CLEARS", "1") not in ("", "0")
+        self._conv_layout_table = [(self._offsets[n + "/weights"][0], ci, co, self._w_fwd[n], self._w_dgrad[n])
+                                   for n, ci, co in conv_shapes[1:]]
         # True (or SLAM_KEEP_FULL_Y=1): pooled batch-norm layers also write their full-resolution output
         self.keep_full_y = os.environ.get("SLAM_KEEP_FULL_Y", "0") not in ("", "0")
         self._built = True
@@ -378,9 +388,7 @@ class VGG16Model:
                 and not self._sync_stats())
 
     def _refresh_operands(self):
-        for a in self._act[1:]:
-            n = a["name"]
-            ops.conv_weight_layouts(self.params[n + "/weights"], self._w_fwd[n], self._w_dgrad[n])
+        ops.conv_weight_layouts_multi(self.flat_params, self._conv_layout_table)     # every layer in one launch
         if not self._fc_shadow_fresh:
             ops.cast_bf16(self.flat_params[:self._fc_end], self._fc_shadow)
             self._fc_shadow_fresh = True
@@ -396,6 +404,18 @@ class VGG16Model:
             self._refresh_operands()
         ops.cast_bf16(self.network_input, self._x)
         h = self._x
+        merged = self.merge_clears and self.batch_norm
+        if merged:
+            ops.zero_fill(self._sums_arena)
+        before = ops.caller_clears_accumulators(True) if merged else None
+        try:
+            h = self._forward_convs(h)
+        finally:
+            if merged:
+                ops.caller_clears_accumulators(before)
+        return self._forward_dense(h)
+
+    def _forward_convs(self, h):
         for i, a in enumerate(self._act):
             n = a["name"]
             if i == 0 and self._recompute_first():
@@ -432,6 +452,9 @@ class VGG16Model:
             if a["pool"]:
                 ops.maxpool2(a["y"], a["pooled"])
                 h = a["pooled"]
+        return h
+
+    def _forward_dense(self, h):
         B = self.batch_size
         h = h.view(B, -1)
         for n in ("fc6-conv", "fc7-conv"):
@@ -506,6 +529,16 @@ class VGG16Model:
         g = d_feat.view_as(last_conv["pooled"] if last_conv["pool"] else last_conv["y"])
         if self.trace is not None:
             self.trace["d_feat"] = g.clone()
+        if self.merge_clears:      # filter gradients, batch-norm sums and bias gradients of every convolution layer
+            ops.zero_fill(self.flat_grads[self._fc_end:])
+        before = ops.caller_clears_accumulators(True) if self.merge_clears else None
+        try:
+            self._backward_convs(g)
+        finally:
+            if self.merge_clears:
+                ops.caller_clears_accumulators(before)
+
+    def _backward_convs(self, g):
         for i in range(len(self._act) - 1, -1, -1):
             a = self._act[i]
             n = a["name"]

@@ -25,6 +25,22 @@ def _call(name, *args):
     capi.check(getattr(capi.load(), name)(*args, capi.current_stream()), name)
 
 
+def zero_fill(t):
+    """Clears a contiguous GPU tensor with the library's kernel (no memset node under graph capture)."""
+    assert t.is_cuda and t.is_contiguous()
+    _call("slamhip_zero_fill", capi.ptr(t), t.numel() * t.element_size())
+
+
+def caller_clears_accumulators(on):
+    """The calling thread clears sums / red / dw accumulators itself; returns the previous setting."""
+    return bool(capi.load().slamhip_caller_clears_accumulators(int(bool(on))))
+
+
+def deterministic():
+    """True when SLAMHIP_DETERMINISTIC=1 selected fixed-order sums for this process."""
+    return bool(capi.load().slamhip_deterministic())
+
+
 def conv_weight_layouts(w_hwio, w_fwd=None, w_dgrad=None):
     """[3,3,Cin,Cout] float32 -> [Cout, 9*Cin] and/or [Cin, 9*Cout] bfloat16 operands."""
     _chk(w_hwio, F32, "w_hwio")
@@ -35,6 +51,27 @@ def conv_weight_layouts(w_hwio, w_fwd=None, w_dgrad=None):
     if w_dgrad is not None:
         assert _chk(w_dgrad, BF16, "w_dgrad").shape == (cin, 9 * cout)
     _call("slamhip_conv_weight_layouts", capi.ptr(w_hwio), capi.ptr(w_fwd), capi.ptr(w_dgrad), cin, cout)
+
+
+def conv_weight_layouts_multi(flat_params, layers):
+    """conv_weight_layouts for several filters of one flat float32 buffer in one launch.
+    layers: [(offset in floats, Cin, Cout, w_fwd or None, w_dgrad or None), ...], at most 16."""
+    import ctypes
+    _chk(flat_params, F32, "flat_params")
+    n = len(layers)
+    assert 0 < n <= 16
+    for off, cin, cout, wf, wd in layers:
+        assert 0 <= off and off + 9 * cin * cout <= flat_params.numel()
+        if wf is not None:
+            assert _chk(wf, BF16, "w_fwd").shape == (cout, 9 * cin)
+        if wd is not None:
+            assert _chk(wd, BF16, "w_dgrad").shape == (cin, 9 * cout)
+    offs = (ctypes.c_longlong * n)(*[l[0] for l in layers])
+    cins = (ctypes.c_int * n)(*[l[1] for l in layers])
+    couts = (ctypes.c_int * n)(*[l[2] for l in layers])
+    wf = (ctypes.c_void_p * n)(*[capi.ptr(l[3]) for l in layers])
+    wd = (ctypes.c_void_p * n)(*[capi.ptr(l[4]) for l in layers])
+    _call("slamhip_conv_weight_layouts_multi", capi.ptr(flat_params), n, offs, cins, couts, wf, wd)
 
 
 def conv3x3(act, w_nk, out_bf16=None, out_f32=None, flip=False):
