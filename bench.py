@@ -109,20 +109,28 @@ def train_loop(fp, buf, K, factor, steps, world=1, dp=None):
         d1, c1, d2, c2, rel = (t[:half].contiguous() for t in (d1, c1, d2, c2, rel))
     B = d1.shape[0]
     dev = d1.device
-    rgb = torch.cat([c1, c2[:, 0]], 0).contiguous()          # 2 B raw frames
-    depth = torch.cat([d1, d2[:, 0]], 0).contiguous()
-    x = torch.zeros(2 * B, 224, 224, 4, dtype=torch.float32, device=dev)
-    model = VGG16Model(2 * B, x, 6, 1e-3, seed=0)
-    model.build_graph()
-    model.add_loss(torch.eye(6, device=dev), torch.zeros(2 * B, 6, device=dev))
-    model.add_optimizer(optimizer='AdamOptimizer')
-    model._optimizer.learning_rate = 1e-5
+    from slam_amd import distributed as sdp
+    try:
+        rgb = torch.cat([c1, c2[:, 0]], 0).contiguous()          # 2 B raw frames
+        depth = torch.cat([d1, d2[:, 0]], 0).contiguous()
+        x = torch.zeros(2 * B, 224, 224, 4, dtype=torch.float32, device=dev)
+        model = VGG16Model(2 * B, x, 6, 1e-3, seed=0)
+        model.build_graph()
+        model.add_loss(torch.eye(6, device=dev), torch.zeros(2 * B, 6, device=dev))
+        model.add_optimizer(optimizer='AdamOptimizer')
+        model._optimizer.learning_rate = 1e-5
+        plan = fp.PairLossPlan(d1, c1, d2, c2, rel, K, factor)
+    except Exception:
+        if dp:
+            sdp.all_ranks_ok(False, device=dev)     # every rank leaves before the first gradient all-reduce
+        raise
+    if dp and not sdp.all_ranks_ok(True, device=dev):
+        raise RuntimeError("train_loop: another rank failed to build its model")
     if not dp:
         step = model.capture_train_step(warmup=2)
     else:
         step = model.train_step
         step(), step()
-    plan = fp.PairLossPlan(d1, c1, d2, c2, rel, K, factor)
 
     def one(ev=None):
         prep.rgbd_batch(rgb, depth, (224, 224), out=x)
@@ -179,6 +187,19 @@ def main():
         torch.cuda.set_device(0)
     if a.gpus != world and rank == 0:
         print("note: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (a.gpus, world), file=sys.stderr)
+    distributed = None
+    if dist is not None:
+        # what the collective library saw: an all-reduce of ones over the default group (= the number of ranks RCCL
+        # connected), its version, and the GPUs' names as a check that every rank sits on a device of its own
+        ones = torch.ones(1, dtype=torch.float32, device=torch.device("cuda", local))
+        dist.all_reduce(ones)
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:       # the version query is informational
+            ver = "unknown (%s)" % type(e).__name__
+        distributed = {"backend": dist.get_backend(), "library": "RCCL (torch's nccl backend on ROCm)",
+                       "rccl_ranks": int(round(float(ones.item()))), "rccl_version": ver,
+                       "world_size": world, "hip": torch.version.hip}
 
     from slam_amd import frame_pairs as fp
     from slam_amd.utils import synthetic as syn
@@ -326,11 +347,11 @@ def main():
                        "roofline": {"bound": "mfma", "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                     "frac": tfl / peak, "flops": "model FLOPs of the whole step / step time, per GPU"}}
             encoder["hip_graph"] = bool(enc.get("hip_graph"))
-            mfma = counters_for(os.path.join(ROOT, "profiles", "r2_encoder_mfma.json"),
+            mfma = counters_for(os.path.join(ROOT, "profiles", "r3_encoder_mfma.json"),
                                 os.path.join(ROOT, "slam_amd", "csrc", "encoder.hip"))
             if mfma is not None:   # MFMA-busy share of the step's kernel time, from rocprofv3 --pmc (tools/pmc_encoder.sh)
                 encoder["roofline"]["mfma_busy_frac"] = mfma["mfma_busy_frac_of_step"]
-                encoder["roofline"]["mfma_busy_source"] = "profiles/r2_encoder_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per kernel, time-weighted)"
+                encoder["roofline"]["mfma_busy_source"] = "profiles/r3_encoder_mfma.json (SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CU_CYCLES per kernel, time-weighted)"
             if world == 1 and rank == 0 and a.cpu_seconds > 0:
                 from oracle import torch_encoder
                 encoder["cpu_baseline"] = torch_encoder.timed_training_steps(8, budget_s=a.cpu_seconds)
@@ -412,6 +433,7 @@ def main():
             "cpu_baseline": cb,
             "cpu_baseline_all_cores": cb_all,
             "verified_against_oracle": verified,
+            "distributed": distributed,
             "overlap_subset": overlap,
             "encoder": encoder,
             "train_step": train,

@@ -175,7 +175,9 @@ int slamhip_pair_loss_reset_workspace(void* workspace, size_t workspace_bytes, v
  * calls no hipMalloc / hipFree.  B * k beyond SLAMHIP_STATIC_MAX_PAIRS is rejected with
  * SLAMHIP_E_SIZE.  All calls on one GPU share that GPU's array: calls that overlap on
  * one GPU (different streams or threads) race and must be serialised by the caller.  The first call on
- * a device looks the array's address up (hipGetSymbolAddress); make that call outside a graph capture. */
+ * a device looks the array's address up (hipGetSymbolAddress); make that call outside a graph capture
+ * (a first call on a capturing stream returns SLAMHIP_E_ARG).  `stream` must belong to the CURRENT device
+ * (every GPU holds its own copy of the array; SLAMHIP_E_ARG otherwise). */
 #define SLAMHIP_STATIC_MAX_PAIRS 8192
 int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, const uint16_t* depth2,
                                    const uint8_t* rgb2, const double* rel4x4, const double K[4],

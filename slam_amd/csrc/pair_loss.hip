@@ -671,7 +671,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       double Bq = fma(ucx, pc.kBc, fma(vcy0, kBr, pc.kB0));
       double C = fma(ucx, pc.kCc, fma(vcy0, kCr, pc.kC0));
       const double t0p = pc.t0p, t1p = pc.t1p, t2 = pc.t2;
-      const double cxw = cam.cx - (double)(wx0 - 1), cyw = cam.cy - (double)(wy0 - 1);
+      // Window-relative coordinates carry an integer bias of 2^16 so that the truncating conversion below IS the
+      // floor for every coordinate above wx0 - 65537 (a coordinate in (-1, 0) would truncate to 0 = floor + 1
+      // otherwise, and a certified pixel there whose other coordinate lies in the last row or column would be
+      // counted as inside the image); below that, floor + 1 is still negative, i.e. outside.  The bias costs no
+      // instruction (it sits in the two constants) and 2^-36 of absolute accuracy, far inside the certificate's bound.
+      constexpr double WBIAS = 65536.0;
+      const double cxw = cam.cx - (double)(wx0 - 1) + WBIAS, cyw = cam.cy - (double)(wy0 - 1) + WBIAS;
       const double dz = pc.dz;
       const float half_eps = pc.half_eps;
       // Software pipeline: row r + 1 is projected and its four cells are requested from LDS before row r
@@ -699,7 +705,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         o.fu = (float)__builtin_amdgcn_fract(uw);
         o.fv = (float)__builtin_amdgcn_fract(vw);
         o.Z = Z;
-        const unsigned int du = (unsigned int)tu - 1u, dv = (unsigned int)tv - 1u;
+        const unsigned int du = (unsigned int)tu - 65537u, dv = (unsigned int)tv - 65537u;   // floor - window origin
         unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
         if (!((rows_nz >> r) & 1u)) m_valid0 = 0ull;
         // certified: z' safely positive and both coordinates farther than the bound from every integer
@@ -1068,13 +1074,27 @@ int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, 
   int dev = -1;
   SLAMHIP_HIP(hipGetDevice(&dev));
   SLAMHIP_REQUIRE(dev >= 0 && dev < MAX_DEVICES, SLAMHIP_E_SIZE, "pair_loss_fused_static: device %d", dev);
+  hipStream_t s = (hipStream_t)stream;
+  if (s) {
+    // every GPU holds its own copy of the array at its own address: the address looked up for the current device
+    // is good only for a stream of that device
+    int sdev = -1;
+    SLAMHIP_HIP(hipStreamGetDevice(s, &sdev));
+    SLAMHIP_REQUIRE(sdev == dev, SLAMHIP_E_ARG,
+                    "pair_loss_fused_static: the stream belongs to device %d, the current device is %d (make the "
+                    "stream's device current before the call)", sdev, dev);
+  }
   void* ptr = scratch_ptr[dev].load(std::memory_order_acquire);
   if (!ptr) {   // first call on this device (racing first calls look up the same address)
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (s) SLAMHIP_HIP(hipStreamIsCapturing(s, &cap));
+    SLAMHIP_REQUIRE(cap == hipStreamCaptureStatusNone, SLAMHIP_E_ARG,
+                    "pair_loss_fused_static: first call on device %d inside a stream capture (the address lookup "
+                    "of the scratch array is no stream operation: call once eagerly before capturing)", dev);
     SLAMHIP_HIP(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
     SLAMHIP_REQUIRE(ptr != nullptr, SLAMHIP_E_HIP, "pair_loss_fused_static: no address for the scratch array");
     scratch_ptr[dev].store(ptr, std::memory_order_release);
   }
-  hipStream_t s = (hipStream_t)stream;
   // the array keeps whatever the last call (possibly an interrupted one) left: clear the records of this call
   SLAMHIP_HIP(clear_records(ptr, sizeof(PairAcc) * (size_t)B * (size_t)k, s));
   return launch_pair_loss("pair_loss_fused_static", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W,

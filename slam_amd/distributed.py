@@ -47,6 +47,43 @@ def finish(handles):
             h.wait()
 
 
+class BucketedAllReduce:
+    """Gradient sum over the ranks in buckets that start while the backward pass still runs.  The flat gradient
+    buffer is laid out in the order the gradients complete; the backward pass reports the offset up to which they
+    are final (`ready`), and a bucket's all-reduce starts as soon as at least `min_elems` new elements are (or
+    `force`), so only the last, small bucket is exposed after the last kernel.  `started` lists the [begin, end)
+    ranges in the order they were issued (every rank issues the same ones: the model fixes them)."""
+
+    def __init__(self, flat, min_elems=1 << 21):
+        self.flat, self.min_elems = flat, int(min_elems)
+        self.begin, self.handles, self.started = 0, [], []
+
+    def ready(self, end, force=False):
+        end = int(end)
+        if end > self.begin and (force or end - self.begin >= self.min_elems):
+            self.handles.append(start_bucket_allreduce(self.flat, self.begin, end))
+            self.started.append((self.begin, end))
+            self.begin = end
+
+    def finish(self, end):
+        self.ready(end, force=True)
+        finish(self.handles)
+        return self.started
+
+
+def require_equal_over_ranks(value, what):
+    """Raises on every rank unless `value` (an int) is the same on all of them."""
+    if not initialised() or world_size() == 1:
+        return
+    t = torch.tensor([int(value), -int(value)], dtype=torch.int64)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    hi, lo = int(t[0].item()), -int(t[1].item())
+    if hi != lo:
+        raise RuntimeError("%s differs between the ranks (%d .. %d; this rank %d)" % (what, lo, hi, int(value)))
+
+
 def total_pair_sums(sums, counts):
     """Sum the per-pair reductions of this rank's shard and add them up over the ranks:
     returns (float64 [4] sums, int64 [4] counts) of the whole job on every rank."""
@@ -84,3 +121,10 @@ def agree_min(value, device=None):
     t = torch.tensor([int(value)], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return int(t.item())
+
+
+def all_ranks_ok(ok, device=None):
+    """True when `ok` holds on every rank.  A step that allocates or builds something per rank (a model, a plan)
+    and then enters a loop of collectives calls this in between - with ok=False from its except handler - so that
+    a failure on one rank makes every rank leave together instead of the others blocking in their first all-reduce."""
+    return bool(agree_min(1 if ok else 0, device=device))

@@ -61,15 +61,21 @@ def timed_training_steps(batch, steps, warmup=2, height=224, width=224, seed=0, 
     """Random-initialised encoder on synthetic input: `steps` training steps (forward, loss,
     backward, gradient all-reduce when torch.distributed is initialised, Adam) timed with
     one event pair on the launching stream.  Returns a dict for benchmark reports."""
-    dev = torch.device("cuda", torch.cuda.current_device())
-    g = torch.Generator(device=dev).manual_seed(data_seed)     # data differ per rank, parameters do not
-    x = torch.randn(batch, height, width, 4, device=dev, generator=g)
-    model = VGG16Model(batch, x, 6, 1e-3, seed=seed)
-    model.build_graph()
-    model.add_loss(torch.eye(6, device=dev), 0.1 * torch.randn(batch, 6, device=dev, generator=g))
-    step = model.add_optimizer()
-    model._optimizer.learning_rate = 1e-5
     from .. import distributed as dp
+    dev = torch.device("cuda", torch.cuda.current_device())
+    try:
+        g = torch.Generator(device=dev).manual_seed(data_seed)     # data differ per rank, parameters do not
+        x = torch.randn(batch, height, width, 4, device=dev, generator=g)
+        model = VGG16Model(batch, x, 6, 1e-3, seed=seed)
+        model.build_graph()
+        model.add_loss(torch.eye(6, device=dev), 0.1 * torch.randn(batch, 6, device=dev, generator=g))
+        step = model.add_optimizer()
+        model._optimizer.learning_rate = 1e-5
+    except Exception:
+        dp.all_ranks_ok(False, device=dev)       # the other ranks must not enter the steps' all-reduces alone
+        raise
+    if not dp.all_ranks_ok(True, device=dev):
+        raise RuntimeError("timed_training_steps: another rank failed to build its model")
     if graph is None:    # replay a recorded step wherever it is supported: one GPU, Adam
         graph = not (dp.initialised() and dp.world_size() > 1) and model._optimizer.kind == 'AdamOptimizer'
     if graph:
@@ -379,7 +385,13 @@ class VGG16Model:
 
     def _sync_stats(self):
         """The normalisation statistics are exchanged between the ranks in this pass."""
-        return self.sync_batch_norm and dp.initialised() and dp.world_size() > 1
+        on = self.sync_batch_norm and dp.initialised() and dp.world_size() > 1
+        if on and not getattr(self, "_sync_checked", False):
+            # the mean of the ranks' sums over ONE rank's row count is the whole batch's mean only if every rank
+            # holds the same number of rows: agreed on once, at the first exchange (every rank gets here together)
+            dp.require_equal_over_ranks(self.batch_size, "sync_batch_norm: the batch size per rank")
+            self._sync_checked = True
+        return on
 
     def _recompute_first(self):
         """The first layer runs without its z tensor in this pass (not under tracing, which keeps z, nor with
@@ -503,10 +515,11 @@ class VGG16Model:
             t = self._scratch[key] = torch.empty_like(like)
         return t
 
-    def backward(self, on_fc_done=None):
+    def backward(self, on_fc_done=None, on_conv_block_done=None):
         """Gradients of `loss` with respect to every parameter, into `grads` (views of
         `flat_grads`).  on_fc_done() is called once the fully connected gradients are
-        complete (the data-parallel step starts their all-reduce there)."""
+        complete, on_conv_block_done(end) after every block of convolution layers with the offset
+        up to which `flat_grads` is final (the data-parallel step starts all-reduces there)."""
         self._d_out_pad[:, :self.output_dim].copy_(self._d_out)
         d = self._d_out_pad
         order = ("out_layer", "fc7-conv", "fc6-conv")
@@ -533,12 +546,18 @@ class VGG16Model:
             ops.zero_fill(self.flat_grads[self._fc_end:])
         before = ops.caller_clears_accumulators(True) if self.merge_clears else None
         try:
-            self._backward_convs(g)
+            self._backward_convs(g, on_conv_block_done)
         finally:
             if self.merge_clears:
                 ops.caller_clears_accumulators(before)
 
-    def _backward_convs(self, g):
+    def _block_done(self, i, on_conv_block_done):
+        """Layer i's gradients are written: at the first layer of a block, report how far flat_grads is final
+        (the layers lie in the buffer in the order the backward pass finishes them)."""
+        if on_conv_block_done is not None and (i == 0 or self._act[i - 1]["pool"]):
+            on_conv_block_done(self._offsets[self._act[i - 1]["name"] + "/weights"][0] if i else self._nparams)
+
+    def _backward_convs(self, g, on_conv_block_done=None):
         for i in range(len(self._act) - 1, -1, -1):
             a = self._act[i]
             n = a["name"]
@@ -556,6 +575,7 @@ class VGG16Model:
                 else:
                     ops.bn_relu_bwd_first_layer(g, a["z"], a["sums"], bn[1], bn[0], self.grads[n + "/bn"], self._x,
                                                 self.grads[n + "/weights"], self.epsilon)
+                self._block_done(i, on_conv_block_done)
                 continue
             if self.batch_norm:
                 bn = self.params[n + "/bn"]
@@ -584,6 +604,7 @@ class VGG16Model:
                 g = d_in
             if self.trace is not None:
                 self.trace[n] = dict(g_out=g_out, dz=dz.clone(), d_in=g.clone() if i else None)
+            self._block_done(i, on_conv_block_done)
 
     # -------------------------------------------------------------- optimizer
     def add_optimizer(self, optimizer=None):
@@ -633,15 +654,16 @@ class VGG16Model:
         self._d_out.copy_(d_output)
 
     def backward_with_allreduce(self):
-        """backward(); under torch.distributed the gradient sum over the ranks runs in two
-        buckets, the fully connected one while the convolution gradients are computed."""
+        """backward(); under torch.distributed the gradient sum over the ranks runs in buckets that start as the
+        backward pass completes them: the fully connected layers first (they overlap the whole convolution
+        backward), then every block of convolution layers of at least 2 Mi elements (blocks 5 and 4; the three
+        wide-image blocks, 1.1 M elements together, go last).  Only that last bucket, 4.6 MB, is exposed after the
+        last kernel.  The issued ranges are kept in `allreduce_buckets`."""
         from .. import distributed as dp
         if dp.initialised():
-            pending = []
-            self.backward(on_fc_done=lambda: pending.append(
-                dp.start_bucket_allreduce(self.flat_grads, 0, self._fc_end)))
-            pending.append(dp.start_bucket_allreduce(self.flat_grads, self._fc_end, self._nparams))
-            dp.finish(pending)
+            buckets = dp.BucketedAllReduce(self.flat_grads)
+            self.backward(on_fc_done=lambda: buckets.ready(self._fc_end, force=True), on_conv_block_done=buckets.ready)
+            self.allreduce_buckets = buckets.finish(self._nparams)
         else:
             self.backward()
 
@@ -669,8 +691,8 @@ class VGG16Model:
         path).  The first `warmup` steps run eagerly (they are ordinary training steps and allocate every
         buffer the recording needs).  Returns the callable that runs one step; the caller refills
         `network_input`, the ground truth and the loss weight in place as before.  The learning rate of
-        every step is written to device memory ahead of the replay (kernel arguments are frozen in a
-        graph).  Every node of the graph is a kernel: the library clears its accumulators with a kernel,
+        every step is written to device memory by a fill kernel queued ahead of the replay (kernel arguments are
+        frozen in a graph; the value rides in that kernel's own argument, so the host may run ahead).  Every node of the graph is a kernel: the library clears its accumulators with a kernel,
         because replays with memset nodes now and then ran ahead of their zero fill."""
         from .. import distributed as dp
         if dp.initialised() and dp.world_size() > 1:
@@ -682,7 +704,6 @@ class VGG16Model:
         for _ in range(max(1, warmup)):      # every lazily allocated buffer exists before the capture
             self.train_step()
         self._lr_t_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self._lr_t_host = torch.zeros(1, dtype=torch.float32).pin_memory()
         self._operands_stale = True          # the operand refresh after an update belongs to every step
 
         def body():
@@ -703,8 +724,9 @@ class VGG16Model:
         def step():
             o = self._optimizer
             lr = o.learning_rate(self.global_step) if callable(o.learning_rate) else o.learning_rate
-            self._lr_t_host[0] = ops.adam_lr_t(lr, self.global_step + 1)
-            self._lr_t_dev.copy_(self._lr_t_host, non_blocking=True)
+            # the value travels as an argument of a fill kernel queued ahead of the replay: no host buffer that a
+            # host running several steps ahead of the GPU could overwrite before an earlier copy has read it
+            self._lr_t_dev.fill_(ops.adam_lr_t(lr, self.global_step + 1))
             graph.replay()
             self.global_step += 1
             return self.loss

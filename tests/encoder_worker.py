@@ -45,7 +45,61 @@ def fullsize(out):
         idx = torch.from_numpy(sample_idx(f.numel(), 20000, 7)).to(dev)
         rec["g_" + name.replace("/", "__")] = f[idx].float().cpu().numpy()
         rec["n_" + name.replace("/", "__")] = np.array([float(f.double().norm())])
+    # exact integer checksums of the bit patterns (order-independent sums of the values read as integers): every
+    # activation the backward pass reads and every gradient, all elements
+    for i, a in enumerate(model._act):
+        for key in ("z", "y", "pooled"):
+            if key in a and not (key == "z" and i == 0) and not (key == "y" and a["pool"]):
+                rec["ck_%s_%s" % (key, a["name"])] = np.array([int(a[key].view(torch.int16).to(torch.int64).sum())])
+    rec["ck_grads"] = np.array([int(model.flat_grads.view(torch.int32).to(torch.int64).sum())])
+    for name, gr in model.grads.items():
+        rec["ck_g_" + name.replace("/", "__")] = np.array([int(gr.contiguous().view(torch.int32).to(torch.int64).sum())])
     np.savez(out, **rec)
+
+
+def graphdet(out):
+    """Training steps replayed from a HIP graph back to back, with no synchronisation in between and a learning
+    rate that changes every step, against the same steps launched eagerly; run with SLAMHIP_DETERMINISTIC=1 the two
+    must agree bit for bit."""
+    import torch
+    from slam_amd.network.cnn_model import VGG16Model
+
+    def make():
+        dev = torch.device("cuda:0")
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(8, 64, 64, 4, generator=g).to(dev)
+        model = VGG16Model(8, x, 6, 1e-3, fc_dim=256, seed=1)
+        model.build_graph()
+        model.add_loss(torch.eye(6, device=dev), torch.randn(8, 6, generator=g).to(dev))
+        model.add_optimizer(optimizer='AdamOptimizer')
+        model._optimizer.learning_rate = lambda step: 1e-4 * (1.0 + (step % 3)) * 0.5 ** (step // 4)   # changes every step
+        return model
+
+    from slam_amd.network import encoder_ops as ops
+    steps = 12
+    eager = make()
+    for _ in range(2):
+        eager.train_step()
+    lr_t_dev = torch.zeros(1, device=eager.device)
+    for _ in range(steps):          # the recorded step's launches, one by one (the step size computed as the replay's)
+        lr = eager._optimizer.learning_rate(eager.global_step)
+        lr_t_dev.fill_(ops.adam_lr_t(lr, eager.global_step + 1))
+        eager.forward()
+        eager.compute_loss(with_gradient=True)
+        eager.backward()
+        ops.adam_step_dev(eager.flat_params, eager.flat_grads, eager._adam_m, eager._adam_v, lr_t_dev,
+                          shadow=eager._fc_shadow)
+        eager._operands_stale, eager._fc_shadow_fresh = True, True
+        eager.global_step += 1
+    torch.cuda.synchronize()
+    replayed = make()
+    step = replayed.capture_train_step(warmup=2)
+    for _ in range(steps):          # the host runs ahead: nothing waits for the GPU between the steps
+        step()
+    torch.cuda.synchronize()
+    np.savez(out, p_eager=eager.flat_params.cpu().numpy(), p_graph=replayed.flat_params.cpu().numpy(),
+             l_eager=eager.loss.cpu().numpy(), l_graph=replayed.loss.cpu().numpy(),
+             steps=np.array([eager.global_step, replayed.global_step]))
 
 
 def layers(out):
@@ -119,6 +173,7 @@ def nccl1(out):
     model.backward_with_allreduce()
     torch.cuda.synchronize()
     g_dp = model.flat_grads.cpu().numpy()
+    buckets, fc_end, n_params = np.array(model.allreduce_buckets), model._fc_end, model._nparams
     model.backward()
     torch.cuda.synchronize()
     g_1 = model.flat_grads.cpu().numpy()
@@ -130,7 +185,8 @@ def nccl1(out):
     assert not dp.initialised()
     model, step = make()
     l_1 = [float(step()) for _ in range(3)]
-    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), g_dp=g_dp, g_1=g_1, p_dp=p_dp)
+    np.savez(out, l_dp=np.array(l_dp), l_1=np.array(l_1), g_dp=g_dp, g_1=g_1, p_dp=p_dp, buckets=buckets,
+             fc_end=fc_end, n_params=n_params)
 
 
 def benchdp(out):
@@ -158,4 +214,4 @@ def benchdp(out):
 
 
 if __name__ == "__main__":
-    {"fullsize": fullsize, "layers": layers, "nccl1": nccl1, "benchdp": benchdp}[sys.argv[1]](sys.argv[2])
+    {"fullsize": fullsize, "layers": layers, "nccl1": nccl1, "benchdp": benchdp, "graphdet": graphdet}[sys.argv[1]](sys.argv[2])

@@ -23,6 +23,9 @@ FALLBACK_ENV = {"SLAMHIP_IGEMM256": "0", "SLAMHIP_IGEMM_ROW3": "0", "SLAMHIP_WGR
                 "SLAMHIP_WGRAD_ROWGROUP": "0", "SLAM_FUSE_FIRST_BWD": "0", "SLAM_FIRST_RECOMPUTE": "0"}
 
 
+DET = {"SLAMHIP_DETERMINISTIC": "1"}
+
+
 def _worker(mode, out, env=None, timeout=600):
     e = dict(os.environ)
     e.update(env or {})
@@ -38,30 +41,68 @@ def _rel(a, b):
 
 
 def test_batch_128_default_dispatch_against_fallback_kernels(tmp_path):
+    """The whole pass under the default dispatch against the same pass on the general kernels, both with fixed-order
+    sums (so that each side is reproducible bit for bit, see the next test, and the distance between them is the
+    kernels' alone).  The two dispatches add the products of a convolution in different orders (per tap, per filter
+    row, 64- or 128-deep steps), so z differs in the last bfloat16 bit here and there, and twelve normalised layers
+    of a randomly initialised network amplify that: the convolution gradients keep their norms (within a few per
+    cent) while their directions drift by up to 0.26.  The tight checks are the per-layer tests below (identical
+    operands: <= 2e-3) and the float32 checks on sampled outputs at these shapes; this one guards the composition."""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    default = _worker("fullsize", str(tmp_path / "default.npz"))
-    again = _worker("fullsize", str(tmp_path / "again.npz"))
-    fallback = _worker("fullsize", str(tmp_path / "fallback.npz"), FALLBACK_ENV)
+    default = _worker("fullsize", str(tmp_path / "default.npz"), DET)
+    fallback = _worker("fullsize", str(tmp_path / "fallback.npz"), dict(FALLBACK_ENV, **DET))
     assert np.isfinite(default["loss"]).all() and np.isfinite(fallback["loss"]).all()
     keys = [k for k in default.files if k.startswith(("z_", "g_", "n_"))] + ["loss", "output"]
     assert len([k for k in keys if k.startswith("z_")]) == 12
     err = {k: _rel(default[k], fallback[k]) for k in keys}
-    floor = {k: _rel(default[k], again[k]) for k in keys}
     print("default dispatch vs fallback kernels, relative L2:", {k: round(v, 5) for k, v in err.items()})
-    print("default dispatch, two runs, relative L2:", {k: round(v, 5) for k, v in floor.items()})
-    # Two runs of one dispatch already differ: the channel statistics are summed with float atomics, a
-    # difference in the last bit flips bfloat16 roundings of z and y, and twelve normalised layers of a
-    # randomly initialised network amplify that in both directions.  The comparison therefore bounds
-    # the fallback's distance by that run-to-run distance (the layer-by-layer test below is the tight one).
     assert err["loss"] < 1e-2 and err["output"] < 6e-2
     assert all(err["z_" + a] < 6e-2 for a in ("conv1_1", "conv1_2", "conv2_1", "conv5_3"))
-    # (measured: z 1e-4 at conv1_2 growing to 3e-2 at conv5_3, output 2.5e-2, dense-layer gradients 2e-2,
-    # convolution gradients 0.1 .. 0.4 in direction at equal norms, for two runs of the same dispatch alike;
-    # the run-to-run distance of the gradients itself varies by some 0.1 between pairs of runs)
+    # measured: z 1e-4 at conv1_2 growing to 3e-2 at conv5_3, output 2.5e-2; gradients of the dense layers 2e-3 ..
+    # 2e-2; of the convolution layers 0.08 (conv5_3) .. 0.26 (conv1_1) in direction at norms within 1e-5 .. 4e-2
+
     def bound(k):
-        return 2.0 * floor[k] + 0.1 if k.startswith(("g_conv", "n_conv")) else 3.0 * floor[k] + 1e-2
-    bad = {k: (v, floor[k]) for k, v in err.items() if not v < bound(k)}
+        if k.startswith("g_conv"):
+            return 0.4
+        if k.startswith("n_conv"):
+            return 0.1
+        return 5e-2
+    bad = {k: v for k, v in err.items() if not v < bound(k)}
     assert not bad, bad
+
+
+def test_batch_128_fixed_order_sums_reproduce_bit_for_bit(tmp_path):
+    """SLAMHIP_DETERMINISTIC=1: every sum that the default mode forms with float atomics (channel statistics,
+    batch-norm backward sums, filter-gradient slices, split-K) is formed in a fixed order instead.  Two processes on
+    the same seeded inputs then give the same bits in every activation the backward pass reads, the loss, the
+    output and every gradient - any difference would be a race (a missing barrier, a stale LDS read), not
+    arithmetic (cnn_model.py:100-124,146-160)."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    a = _worker("fullsize", str(tmp_path / "a.npz"), DET)
+    b = _worker("fullsize", str(tmp_path / "b.npz"), DET)
+    assert sorted(a.files) == sorted(b.files)
+    assert len([k for k in a.files if k.startswith("ck_")]) >= 11 + 7 + 5 + 1 + 30   # z, y, pooled, all gradients
+    differ = [k for k in a.files if not np.array_equal(a[k], b[k])]
+    assert not differ, differ
+    assert np.isfinite(a["loss"]).all() and float(np.abs(a["g_conv1_1__weights"]).max()) > 0
+    # the same network in the default mode: the fixed-order sums are the same sums (first layers agree closely; the
+    # run-to-run floor of the atomics applies to the deep ones, see the test above)
+    d = _worker("fullsize", str(tmp_path / "d.npz"))
+    assert _rel(d["z_conv1_1"], a["z_conv1_1"]) < 1e-3 and _rel(d["z_conv1_2"], a["z_conv1_2"]) < 1e-2
+    assert _rel(d["loss"], a["loss"]) < 1e-2
+
+
+def test_graph_replays_back_to_back_equal_eager_steps_bit_for_bit(tmp_path):
+    """Twelve replayed training steps with no synchronisation in between and a learning rate that changes at every
+    step, against the same steps launched eagerly, under fixed-order sums: identical parameters.  (The step size of
+    a replay is device data written by a fill kernel ahead of it; a reused pinned host slot could be overwritten
+    by a host that runs ahead.)"""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    r = _worker("graphdet", str(tmp_path / "g.npz"), DET)
+    assert list(r["steps"]) == [14, 14]
+    assert np.isfinite(r["p_graph"]).all()
+    assert np.array_equal(r["l_eager"], r["l_graph"])
+    assert np.array_equal(r["p_eager"], r["p_graph"])
 
 
 def test_batch_128_each_layer_default_dispatch_against_fallback_kernels(tmp_path):
@@ -119,6 +160,62 @@ def test_batch_128_layers_against_float32_on_sampled_pixels():
     assert torch.isfinite(model.network_output).all()
 
 
+def test_batch_128_gradients_against_float32_on_sampled_outputs():
+    """Data gradient and filter gradient of every convolution shape of the encoder at batch 128 (the kernels the
+    dispatch picks there: 256-wide tiles, filter-row kernels, row-group and 112-pixel filter gradients) against
+    float32 / float64 arithmetic on the CPU: 128 sampled pixels (all input channels) of the data gradient, all nine
+    taps of sampled (input channel, output channel) pairs of the filter gradient, on random bfloat16 operands
+    (cnn_model.py:100, 146-160: the gradients TensorFlow derives for conv2d)."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from slam_amd.network import encoder_ops as ops
+    B = 128
+    dev = torch.device("cuda:0")
+    shapes = [(224, 4, 64), (224, 64, 64), (112, 64, 128), (112, 128, 128), (56, 128, 256), (56, 256, 256),
+              (28, 256, 512), (28, 512, 512), (14, 512, 512)]
+    rs = np.random.RandomState(5)
+    g = torch.Generator(device=dev).manual_seed(11)
+    for HW, Cin, Cout in shapes:
+        H = W = HW
+        x = torch.randn(B, H, W, Cin, device=dev, generator=g).to(torch.bfloat16)
+        dz = torch.randn(B, H, W, Cout, device=dev, generator=g).to(torch.bfloat16)
+        w = (0.05 * torch.randn(3, 3, Cin, Cout, device=dev, generator=g)).to(torch.bfloat16).float()
+        dw = torch.empty(3, 3, Cin, Cout, device=dev)
+        # ---- filter gradient: dw[ky,kx,ci,co] = sum_{b,y,x} x[b,y+ky-1,x+kx-1,ci] dz[b,y,x,co]
+        if Cin == 4:
+            ops.conv3x3_small_wgrad(x, dz, dw)
+        else:
+            ops.wgrad(x, dz, dw)
+        pairs = 8 if HW >= 112 else 24
+        cis, cos = rs.randint(0, Cin, pairs), rs.randint(0, Cout, pairs)
+        want = np.zeros((pairs, 3, 3))
+        for k, (ci, co) in enumerate(zip(cis, cos)):
+            xi = torch.nn.functional.pad(x[..., int(ci)].float(), (1, 1, 1, 1)).cpu().double()
+            dzo = dz[..., int(co)].float().cpu().double()
+            for ky in range(3):
+                for kx in range(3):
+                    want[k, ky, kx] = float((xi[:, ky:ky + H, kx:kx + W] * dzo).sum())
+        got = dw.cpu().numpy()[:, :, cis, cos].transpose(2, 0, 1)
+        err = float(np.linalg.norm(got - want) / np.linalg.norm(want))
+        assert err < 1e-3, ("filter gradient", HW, Cin, Cout, err)
+        if Cin == 4:
+            continue
+        # ---- data gradient: d_in[y,x,ci] = sum_{ky,kx,co} dz[y-ky+1,x-kx+1,co] w[ky,kx,ci,co]
+        w_dg = torch.empty(Cin, 9 * Cout, dtype=torch.bfloat16, device=dev)
+        ops.conv_weight_layouts(w, None, w_dg)
+        d_in = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        ops.conv3x3(dz, w_dg, out_bf16=d_in, flip=True)
+        n = 128
+        bs, ys, xs = rs.randint(0, B, n), rs.randint(0, H, n), rs.randint(0, W, n)
+        ys[:8], xs[:8] = [0, 0, H - 1, H - 1, 0, H - 1, 1, H // 2], [0, W - 1, 0, W - 1, W // 2, 1, 0, W - 1]   # borders
+        dzp = torch.nn.functional.pad(dz, (0, 0, 1, 1, 1, 1))
+        patches = torch.stack([dzp[int(b), int(y):int(y) + 3, int(xx):int(xx) + 3, :] for b, y, xx in zip(bs, ys, xs)])
+        want_d = torch.einsum("nabo,abio->ni", patches.float().cpu(), w.cpu().flip(0, 1))
+        got_d = d_in[torch.from_numpy(bs).to(dev), torch.from_numpy(ys).to(dev), torch.from_numpy(xs).to(dev)].float().cpu()
+        err = float((got_d - want_d).norm() / want_d.norm())
+        assert err < 6e-3, ("data gradient", HW, Cin, Cout, err)       # bfloat16 storage: 2^-9 per element
+        del dzp, patches, d_in
+
+
 def test_train_step_under_rccl_group_of_one(tmp_path):
     """VGG16Model.train_step() with torch.distributed initialised (backend nccl = RCCL, world size 1):
     backward_with_allreduce() issues the two bucketed all-reduces; the steps match those without a group."""
@@ -127,6 +224,11 @@ def test_train_step_under_rccl_group_of_one(tmp_path):
     # the same activations differentiated with and without the all-reduce: the float atomics of the
     # backward pass alone separate the two
     assert np.isfinite(r["g_dp"]).all() and np.abs(r["g_dp"]).max() > 0
+    # four buckets, issued as the backward pass completes them: dense layers, block 5, block 4, blocks 3 to 1;
+    # contiguous, covering every gradient once
+    b = r["buckets"]
+    assert b.shape == (4, 2) and b[0, 0] == 0 and b[0, 1] == int(r["fc_end"]) and b[-1, 1] == int(r["n_params"])
+    assert (b[1:, 0] == b[:-1, 1]).all() and (b[1:3, 1] - b[1:3, 0] >= 1 << 21).all() and b[3, 1] - b[3, 0] < 1 << 21
     assert _rel(r["g_dp"], r["g_1"]) < 2e-2
     # whole steps: the first loss comes from the same parameters (the order of the float atomics in the
     # channel statistics moves it in the fourth digit); training proceeds

@@ -515,3 +515,48 @@ def test_first_layer_without_stored_z(ops, B, H, W):
     scale = float(red_ref.abs().max())
     np.testing.assert_allclose(red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-4, atol=1e-5 * scale)
     np.testing.assert_allclose(dw.cpu().numpy(), dw_ref.cpu().numpy(), rtol=1e-3, atol=1e-3 * float(dw_ref.abs().max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pool", [False, True])
+def test_batch_norm_backward_in_two_phases_over_two_shards_matches_the_whole_batch(ops, pool):
+    """What two ranks with shared statistics compute for one layer (cnn_model.py:100-113 on the whole batch): each
+    shard runs the reduction pass on its half, the sums are averaged (every rank divides by its OWN row count, so
+    the mean of the ranks' sums stands for the whole batch's), each shard runs the apply pass - against the one-call
+    backward on the whole batch.  Tight, because a single layer does not amplify rounding."""
+    g = torch.Generator().manual_seed(77)
+    dev = "cuda"
+    B, H, W, C = 4, 16, 24, 128
+    z = torch.randn(B, H, W, C, generator=g).to(dev).to(torch.bfloat16)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    dy_shape = (B, H // 2, W // 2, C) if pool else (B, H, W, C)
+    dy = torch.randn(*dy_shape, generator=g).to(dev).to(torch.bfloat16)
+    bwd = ops.bn_relu_pool_bwd if pool else ops.bn_relu_bwd
+    sums = torch.empty(2, C, device=dev)
+    ops.channel_stats(z, sums)
+    red_ref, dz_ref = torch.empty(2, C, device=dev), torch.empty_like(z)
+    bwd(dy, z, sums, gamma, beta, red_ref, dz_ref, 1e-3)
+    # two shards: statistics and backward sums averaged, as dp.average_over_ranks does
+    h = B // 2
+    shard_sums = [torch.empty(2, C, device=dev) for _ in range(2)]
+    for r in range(2):
+        ops.channel_stats(z[r * h:(r + 1) * h].contiguous(), shard_sums[r])
+    mean_sums = (shard_sums[0] + shard_sums[1]) / 2
+    reds = [torch.empty(2, C, device=dev) for _ in range(2)]
+    dz = torch.empty_like(z)
+    parts = []
+    for r in range(2):
+        zs, dys = z[r * h:(r + 1) * h].contiguous(), dy[r * h:(r + 1) * h].contiguous()
+        out = torch.empty_like(zs)
+        bwd(dys, zs, mean_sums, gamma, beta, reds[r], out, 1e-3, phases=1)
+        parts.append((dys, zs, out))
+    mean_red = (reds[0] + reds[1]) / 2
+    for r, (dys, zs, out) in enumerate(parts):
+        bwd(dys, zs, mean_sums, gamma, beta, mean_red.clone(), out, 1e-3, phases=2)
+        dz[r * h:(r + 1) * h] = out
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(2 * mean_sums.cpu().numpy(), sums.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(2 * mean_red.cpu().numpy(), red_ref.cpu().numpy(), rtol=1e-3, atol=2e-2)
+    err = float((dz.float() - dz_ref.float()).norm() / dz_ref.float().norm())
+    assert err < 1e-2, err

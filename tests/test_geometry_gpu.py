@@ -398,3 +398,84 @@ def test_decision_boundaries_adversarial(fp):
     rel5[:, :, :3, 3] /= 5000.0
     _check_warp(fp, d1, c1, d2, c2, rel5, K, 5000.0)
     _check_fused(fp, d1, c1, d2, c2, rel5, K, 5000.0)
+
+
+@pytest.mark.parametrize("factor", [1.0, 5000.0])
+def test_coordinates_just_below_zero_beside_the_far_border(fp, factor):
+    """Pixels that project to u in (-1, 0) while v lies in the last row [H-1, H) (and the mirror image: v in (-1, 0),
+    u in the last column), placed inside tiles whose other pixels project well inside the image, so that the tile's
+    tap window does not start at the border.  Such a pixel fails `0 <= u` (test_import.py:174); a floor taken by
+    truncation would give index 0 for it.  One target pixel per column (row) under a pure translation:
+    u = col + tx fx / z with the integer raw depth z nearest to fx |tx| / (col + 0.5)."""
+    H, W = 96, 256
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    fx, fy = K[0], K[1]
+    rs = np.random.RandomState(3)
+    B = 4
+    d1 = np.full((B, H, W), 60000, np.uint16)
+    rel = np.tile(np.eye(4), (B, 1, 1, 1))
+    hits = 0
+    for b in range(B):
+        mirror = b % 2 == 1
+        t_main, t_side = 3000.0 + 100.0 * b, 60.0 + 7.0 * b
+        if not mirror:      # u just below 0, v in the last row
+            rel[b, 0, 0, 3], rel[b, 0, 1, 3] = -t_main, t_side
+            for c in range(24, W):
+                z = int(round(fx * t_main / (c + 0.5)))
+                shift_v = t_side * fy / z
+                row = H - 1 - int(np.floor(shift_v))
+                u, v = c - t_main * fx / z, row + shift_v
+                if 1 <= z <= 65535 and 0 <= row < H and -1 < u < 0 and H - 1 <= v < H:
+                    d1[b, row, c] = z
+                    hits += 1
+        else:               # v just below 0, u in the last column
+            rel[b, 0, 1, 3], rel[b, 0, 0, 3] = -t_main / 4, t_side
+            for r in range(12, H):
+                z = int(round(fy * t_main / 4 / (r + 0.5)))
+                shift_u = t_side * fx / z
+                col = W - 1 - int(np.floor(shift_u))
+                u, v = col + shift_u, r - t_main / 4 * fy / z
+                if 1 <= z <= 65535 and 0 <= col < W and -1 < v < 0 and W - 1 <= u < W:
+                    d1[b, r, col] = z
+                    hits += 1
+    assert hits > 300
+    rel[:, :, :3, 3] /= factor
+    d1[:, ::9, ::11] = 0
+    d2 = rs.randint(2500, 25001, size=(B, 1, H, W)).astype(np.uint16)
+    c1 = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
+    o = _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+    # the construction does what it says, in the oracle's own coordinates
+    u, v = o["uvd"][..., 0], o["uvd"][..., 1]
+    corner = ((u > -1) & (u < 0) & (v >= H - 1) & (v < H)) | ((v > -1) & (v < 0) & (u >= W - 1) & (u < W))
+    assert int(corner.sum()) > 250
+    _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+
+
+def test_near_pixels_under_a_small_translation_project_just_above_the_image(fp):
+    """A translation so small that a tile's tap window does not depend on depth (it is placed from the tile's
+    corners, two rows above the tile) while a few very near pixels (raw depth 2 or 3) still move by r + 0.5 rows:
+    a row r of the second tile row lands at v = -0.5, and its last pixel at u in [W-1, W).  That pixel is outside
+    the image (`0 <= v` fails, test_import.py:174) although the truncated window-relative row index is 0."""
+    H, W = 96, 128
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    fx, fy = K[0], K[1]
+    rs = np.random.RandomState(4)
+    # (the window is placed without the depths while max(fx, fy) (|tx| + |ty| + |tz|) / 256 < 0.5)
+    cases = [(r, z) for r in range(16, 48) for z in (2, 3) if ((r + 0.5) / fy + 0.4 / fx) * z * max(fx, fy) / 256.0 < 0.45]
+    B = len(cases)
+    assert B >= 20
+    d1 = rs.randint(20000, 60000, size=(B, H, W)).astype(np.uint16)
+    rel = np.tile(np.eye(4), (B, 1, 1, 1))
+    for b, (r, z) in enumerate(cases):
+        rel[b, 0, 1, 3] = -(r + 0.5) * z / fy        # v = row - (r + 0.5) at depth z
+        rel[b, 0, 0, 3] = 0.4 * z / fx               # u = col + 0.4
+        d1[b, r, :] = z
+    d2 = rs.randint(2500, 25001, size=(B, 1, H, W)).astype(np.uint16)
+    c1 = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
+    o = _check_warp(fp, d1, c1, d2, c2, rel, K, 1.0)
+    u, v = o["uvd"][:, 0, ..., 0], o["uvd"][:, 0, ..., 1]
+    for b, (r, z) in enumerate(cases):
+        assert -1 < v[b, r, W - 1] < 0 and W - 1 <= u[b, r, W - 1] < W
+    _check_fused(fp, d1, c1, d2, c2, rel, K, 1.0)

@@ -137,8 +137,24 @@ def _rank_main(rank, world, port, out_dir):
             g = torch.ones(3) * (rank + 1)
             dist.all_reduce(g)               # stands for the step's gradient all-reduce
             steps += 1
+        # (4) the gradient buckets of the training step: ranges become final in the order of the flat buffer,
+        #     a bucket starts once 2 Mi elements are ready (or on request), the rest goes last
+        n_grad = (5 << 20) + 77
+        grad = torch.arange(n_grad, dtype=torch.float32) % 1000 * (rank + 1)
+        buckets = dp.BucketedAllReduce(grad)
+        buckets.ready(1 << 20, force=True)            # "fully connected layers done"
+        for end in ((1 << 20) + (3 << 20), (1 << 20) + (3 << 20) + 1000, n_grad - 5):
+            buckets.ready(end)                          # "a block of convolution layers done"
+        started = buckets.finish(n_grad)
+        dp.require_equal_over_ranks(n_grad, "gradient elements")
+        unequal = ""
+        try:
+            dp.require_equal_over_ranks(4 + rank, "batch size per rank")
+        except RuntimeError as ex:
+            unequal = str(ex)
         np.savez(os.path.join(out_dir, "rank%d.npz" % rank), tot_s=tot_s.numpy(), tot_c=tot_c.numpy(),
-                 flat=flat.numpy(), shard=np.array([b, e]), own_len=own, steps=steps)
+                 flat=flat.numpy(), shard=np.array([b, e]), own_len=own, steps=steps, grad=grad.numpy(),
+                 started=np.array(started), unequal=np.array(unequal))
     finally:
         dist.destroy_process_group()
 
@@ -159,4 +175,8 @@ def test_two_rank_gloo_sharding_and_reductions(tmp_path):
         np.testing.assert_array_equal(g["flat"], np.arange(10, dtype=np.float32) * 3)   # (1 + 2) x
         shards.append(tuple(g["shard"]))
         assert int(g["steps"]) == 4 and int(g["own_len"]) == (4, 7)[r]    # both ranks stop after the shorter sequence
+        n_grad = (5 << 20) + 77
+        np.testing.assert_array_equal(g["grad"], (np.arange(n_grad) % 1000 * 3).astype(np.float32))   # (1 + 2) x, every element once
+        assert [tuple(x) for x in g["started"]] == [(0, 1 << 20), (1 << 20, 4 << 20), (4 << 20, n_grad)]
+        assert "batch size per rank differs between the ranks (4 .. 5" in str(g["unequal"])
     assert shards == [(0, 3), (3, 5)]

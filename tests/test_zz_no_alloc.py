@@ -1,7 +1,8 @@
 """The allocation-free entry point of the fused frame-pair kernel against the
 entry point that takes a caller's workspace: counts bit-exact, sums to 1e-9
 relative (float64 atomics add in a different order from launch to launch), on two
-calls in a row, the second with a smaller input.  Through the C ABI."""
+calls in a row, the second with a smaller input; and against the oracle (counts bit-exact,
+sums to 1e-4).  Through the C ABI."""
 import numpy as np
 import pytest
 
@@ -51,6 +52,11 @@ def _both(lib, t, B, k, H, W, K, factor):
     assert np.array_equal(c0, c1)
     assert (c0[..., 0] > 0).all()
     np.testing.assert_allclose(s1, s0, rtol=1e-9)
+    # ... and against the oracle itself: counts bit for bit, sums within the float32 tolerance of the path
+    from oracle import slam_oracle as so
+    want_s, want_c = so.pair_loss(*[x.cpu().numpy() for x in t], K, factor)
+    assert np.array_equal(c1.astype(np.int64) & 0xFFFFFFFF, want_c.astype(np.int64))
+    np.testing.assert_allclose(s1, want_s, rtol=1e-4, atol=1e-6)
 
 
 def test_static_entry_matches_workspace_entry():
