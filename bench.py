@@ -292,10 +292,13 @@ def main():
             planes = [(bufs[i % len(bufs)][0] if i < len(bufs) else bufs[i % len(bufs)][0].clone(), bufs[i % len(bufs)][4])
                       for i in range(n_copies)]
 
+            ovl_ws = torch.zeros((lib.slamhip_overlap_fused_workspace_bytes(B),), dtype=torch.uint8, device=dev)
+
             def ovl(i):
                 dpl, rl = planes[i % n_copies]
-                capi.check(lib.slamhip_overlap_fused(dpl.data_ptr(), rl.data_ptr(), K4, float(a.factor), float(W), float(H),
-                                                     B, H, W, oc.data_ptr(), stream), "slamhip_overlap_fused")
+                capi.check(lib.slamhip_overlap_fused_ws(dpl.data_ptr(), rl.data_ptr(), K4, float(a.factor), float(W), float(H),
+                                                        B, H, W, oc.data_ptr(), ovl_ws.data_ptr(), ovl_ws.numel(), stream),
+                           "slamhip_overlap_fused_ws")
             n_ovl = 400
             for i in range(100):
                 ovl(i)
@@ -312,13 +315,13 @@ def main():
             torch.cuda.synchronize()       # (a plan may launch on a side stream)
             same = bool(torch.equal(oc, fused_counts.reshape(B, -1)[:, :2].to(torch.int32)))
             ovl_bytes = B * H * W * 2
-            overlap = {"workload": "slamhip_overlap_fused on the %d anchor depth planes of a batch (counts of _point_cloud -> "
+            overlap = {"workload": "slamhip_overlap_fused_ws on the %d anchor depth planes of a batch (counts of _point_cloud -> "
                                    "_transform_pointcloud -> _backtransform_pointcloud -> _overlap, no intermediates)" % B,
                        "pairs_per_s": B / (call_ms * 1e-3), "call_ms": call_ms, "calls": n_ovl, "depth_batches_rotated": n_copies,
                        "roofline": {"bound": "hbm", "achieved": ovl_bytes / (call_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                     "unit": "GB/s", "frac": ovl_bytes / (call_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "algorithmic_bytes_per_call": ovl_bytes,
-                                    "note": "a call is a counter-clearing kernel plus overlap_fused_kernel"},
+                                    "note": "a call is one launch of overlap_fused_kernel (counters and ticket in a caller's workspace)"},
                        "counts_equal_fused_kernel": same}
             if not same:
                 overlap["error"] = "counts differ from the fused kernel's"

@@ -135,6 +135,16 @@ int slamhip_overlap_count(const double* uvd, long long n, double dim_u, double d
 int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
                           double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* stream);
 
+/* The same in ONE launch: the per-frame counters and a ticket live in `workspace` (16 bytes per frame,
+ * slamhip_overlap_fused_workspace_bytes, 16-byte aligned) which the caller zero-fills once (slamhip_zero_fill);
+ * every call leaves it zero-filled again - the workgroup that finishes a frame last moves the totals to `counts` and
+ * clears the record - so there is no clearing kernel.  Calls that share a workspace must not overlap; after a failed
+ * or interrupted call zero-fill it again. */
+size_t slamhip_overlap_fused_workspace_bytes(int B);
+int slamhip_overlap_fused_ws(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                             double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* ---- device: fused frame-pair kernel (the benchmarked path) --------------- */
 
 /* Bytes of workspace slamhip_pair_loss_fused needs for a batch of B anchors with

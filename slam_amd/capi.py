@@ -43,6 +43,9 @@ SIGNATURES = {
                                _c_void_p], _c_int),
     "slamhip_overlap_fused": ([_c_void_p, _c_void_p, _K4, _c_double, _c_double, _c_double, _c_int, _c_int, _c_int, _c_void_p,
                                _c_void_p], _c_int),
+    "slamhip_overlap_fused_workspace_bytes": ([_c_int], ctypes.c_size_t),
+    "slamhip_overlap_fused_ws": ([_c_void_p, _c_void_p, _K4, _c_double, _c_double, _c_double, _c_int, _c_int, _c_int,
+                                  _c_void_p, _c_void_p, ctypes.c_size_t, _c_void_p], _c_int),
     "slamhip_pair_loss_workspace_bytes": ([_c_int, _c_int], ctypes.c_size_t),
     "slamhip_pair_loss_fused": ([_c_void_p, _c_void_p, _c_void_p, _c_void_p, _c_void_p, _K4, _c_double,
                                  _c_int, _c_int, _c_int, _c_int, _c_void_p, _c_void_p, _c_void_p,

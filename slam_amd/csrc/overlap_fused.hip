@@ -105,7 +105,7 @@ __device__ __forceinline__ unsigned int wave_usum63(unsigned int v) {
 // packed pairs.
 __global__ void __launch_bounds__(256)
 overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const double* __restrict__ rel,
-                     unsigned int* __restrict__ counts) {
+                     unsigned int* __restrict__ counts, unsigned int* __restrict__ acc) {
   constexpr int RPW = OVL_RPW;
   __shared__ OvlConsts s_c;
   __shared__ unsigned int s_cnt[4][2];
@@ -310,7 +310,26 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   __syncthreads();
   if (tid < 2) {
     const unsigned int c = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
-    if (c) atomicAdd(&counts[2 * (long long)b + tid], c);
+    if (acc) {
+      // the caller's zero-filled record {valid, inside, ticket, -} of this frame: the workgroup that draws the
+      // last ticket moves the totals to `counts` and leaves the record zero-filled for the next call - one
+      // launch, no clearing kernel
+      if (c) atomicAdd(&acc[4 * (long long)b + tid], c);
+    } else if (c) {
+      atomicAdd(&counts[2 * (long long)b + tid], c);
+    }
+  }
+  if (acc && wave == 0) {
+    // the two adds (lanes 0 and 1 of this wave) have been performed at the L2 before the ticket is drawn: the
+    // wave waits for their acknowledgement (stores and atomics without a result count in vmcnt on gfx9)
+    __builtin_amdgcn_s_waitcnt(0);
+    unsigned int t = 0;
+    if (lane == 0) t = atomicAdd(&acc[4 * (long long)b + 2], 1u);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t == gridDim.x * gridDim.y - 1u) {       // every other workgroup of the frame drew its ticket after its adds
+      if (lane < 2) counts[2 * (long long)b + lane] = atomicExch(&acc[4 * (long long)b + lane], 0u);
+      else if (lane == 2) atomicExch(&acc[4 * (long long)b + 2], 0u);
+    }
   }
 }
 
@@ -318,8 +337,9 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
 
 using namespace slamhip;
 
-extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
-                                     double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* stream) {
+static int launch_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                                double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, unsigned int* acc,
+                                void* stream) {
   SLAMHIP_REQUIRE(B >= 0 && H > 0 && W > 0, SLAMHIP_E_ARG, "overlap_fused: bad shape B=%d H=%d W=%d", B, H, W);
   if (B == 0) return SLAMHIP_OK;
   SLAMHIP_REQUIRE(depth && rel4x4 && K && counts, SLAMHIP_E_ARG, "overlap_fused: null pointer");
@@ -352,10 +372,28 @@ extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
   a.pair_loads = (W % 2 == 0) && W >= 2 && (reinterpret_cast<uintptr_t>(depth) % 4) == 0;
-  // the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds kernel nodes only)
-  clear_u32_async(counts, 2LL * B, s);
+  // without a workspace the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds
+  // kernel nodes only); with one the call is this launch alone
+  if (!acc) clear_u32_async(counts, 2LL * B, s);
   hipLaunchKernelGGL(overlap_fused_kernel, dim3((unsigned)tiles_x, (unsigned)tiles_y, (unsigned)B), dim3(256), 0, s, a,
-                     depth, rel4x4, counts);
+                     depth, rel4x4, counts, acc);
   SLAMHIP_HIP(hipGetLastError());
   return SLAMHIP_OK;
+}
+
+extern "C" int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                                     double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* stream) {
+  return launch_overlap_fused(depth, rel4x4, K, factor, dim_u, dim_v, B, H, W, counts, nullptr, stream);
+}
+
+extern "C" size_t slamhip_overlap_fused_workspace_bytes(int B) { return B > 0 ? 16 * (size_t)B : 0; }
+
+extern "C" int slamhip_overlap_fused_ws(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
+                                        double dim_u, double dim_v, int B, int H, int W, uint32_t* counts,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+  SLAMHIP_REQUIRE(B <= 0 || (workspace && workspace_bytes >= slamhip_overlap_fused_workspace_bytes(B) &&
+                             (reinterpret_cast<uintptr_t>(workspace) % 16) == 0),
+                  SLAMHIP_E_ARG, "overlap_fused_ws: workspace of %zu bytes (need %zu, 16-byte aligned)", workspace_bytes,
+                  slamhip_overlap_fused_workspace_bytes(B));
+  return launch_overlap_fused(depth, rel4x4, K, factor, dim_u, dim_v, B, H, W, counts, (unsigned int*)workspace, stream);
 }

@@ -101,6 +101,9 @@ def overlap_count(uvd, dim, want_mask=False):
     return cnt, mask
 
 
+_overlap_ws = {}
+
+
 def overlap_fused(depth, rel, K, dim, factor=FACTOR):
     """depth uint16 [B,H,W], rel float64 [B,4,4] -> counts int32 [B,2] = {points the reference's _point_cloud
     keeps, of those the ones projected into [0, dim[0]] x [0, dim[1]]} (test_import.py:148-176 in one pass over
@@ -114,9 +117,19 @@ def overlap_fused(depth, rel, K, dim, factor=FACTOR):
         raise ValueError("rel must be [B,4,4]")
     counts = torch.empty((B, 2), dtype=torch.int32, device=d.device)
     lib = capi.load()
-    capi.check(lib.slamhip_overlap_fused(d.data_ptr(), r.data_ptr(), capi.K4(K), float(factor), float(dim[0]),
-                                         float(dim[1]), B, H, W, counts.data_ptr(), capi.current_stream()),
-               "slamhip_overlap_fused")
+    # one launch: the counters' records live in a zero-filled workspace that every call leaves zero-filled (one per
+    # device and stream, so that calls on different streams do not share records)
+    key = (d.device.index, capi.current_stream())
+    ws = _overlap_ws.get(key)
+    if ws is None or ws.numel() < 16 * B:
+        ws = _overlap_ws[key] = torch.zeros((max(16 * B, 4096),), dtype=torch.uint8, device=d.device)
+    try:
+        capi.check(lib.slamhip_overlap_fused_ws(d.data_ptr(), r.data_ptr(), capi.K4(K), float(factor), float(dim[0]),
+                                                float(dim[1]), B, H, W, counts.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                capi.current_stream()), "slamhip_overlap_fused_ws")
+    except Exception:
+        ws.zero_()
+        raise
     return counts
 
 

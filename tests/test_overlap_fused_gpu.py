@@ -7,6 +7,7 @@ import pytest
 torch = pytest.importorskip("torch")
 
 from oracle import slam_oracle as so
+from slam_amd import capi
 from slam_amd.utils import synthetic as syn
 
 pytestmark = pytest.mark.gpu
@@ -44,10 +45,41 @@ def _rels(n, seed, max_deg=3.0, max_t=0.05):
 
 
 def _check(fp, depth, rel, K, dim, factor):
-    got = _u32(fp.overlap_fused(_dev(depth), _dev(rel), K, dim, factor))
+    d, r = _dev(depth), _dev(rel)
+    got = _u32(fp.overlap_fused(d, r, K, dim, factor))       # one launch, counters in a workspace
     want = np.array([_oracle_counts(depth[b], rel[b], K, dim, factor) for b in range(depth.shape[0])], np.int64)
     assert np.array_equal(got, want), (got.tolist(), want.tolist())
+    # the entry point without a workspace (clearing kernel + atomics into the output) counts the same
+    B, H, W = depth.shape
+    lib = capi.load()
+    plain = torch.full((B, 2), -1, dtype=torch.int32, device=d.device)
+    capi.check(lib.slamhip_overlap_fused(d.data_ptr(), r.data_ptr(), capi.K4(K), float(factor), float(dim[0]), float(dim[1]),
+                                         B, H, W, plain.data_ptr(), capi.current_stream()), "slamhip_overlap_fused")
+    assert np.array_equal(_u32(plain), want)
     return got
+
+
+def test_workspace_entry_leaves_its_records_cleared(fp):
+    """Calls of different sizes in a row on one workspace: every call leaves the records zero-filled (the workgroup
+    that finishes a frame last publishes and clears), so the next call starts from zero without a clearing launch."""
+    lib = capi.load()
+    H, W = 70, 200
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    ws = torch.zeros((lib.slamhip_overlap_fused_workspace_bytes(9),), dtype=torch.uint8, device="cuda")
+    for B, seed in ((9, 1), (2, 2), (5, 3), (9, 4)):
+        depth = syn.depth_frames(B, H, W, seed=seed, kind="noise")
+        rel = _rels(B, seed=seed, max_t=300.0, max_deg=8.0)
+        d, r = _dev(depth), _dev(rel)
+        got = torch.full((B, 2), -1, dtype=torch.int32, device="cuda")
+        capi.check(lib.slamhip_overlap_fused_ws(d.data_ptr(), r.data_ptr(), capi.K4(K), 1.0, float(W), float(H), B, H, W,
+                                                got.data_ptr(), ws.data_ptr(), ws.numel(), capi.current_stream()),
+                   "slamhip_overlap_fused_ws")
+        torch.cuda.synchronize()
+        want = np.array([_oracle_counts(depth[b], rel[b], K, (float(W), float(H)), 1.0) for b in range(B)], np.int64)
+        assert np.array_equal(_u32(got), want)
+        assert int(ws.to(torch.int64).sum()) == 0
+    assert lib.slamhip_overlap_fused_ws(d.data_ptr(), r.data_ptr(), capi.K4(K), 1.0, float(W), float(H), 9, H, W,
+                                        got.data_ptr(), ws.data_ptr(), 16, None) < 0          # workspace too small
 
 
 @pytest.mark.parametrize("H,W,factor,kind", [(5, 7, 1.0, "noise"), (48, 64, 1.0, "plane"), (33, 130, 5000.0, "noise"),
