@@ -99,6 +99,17 @@ __device__ __forceinline__ unsigned int wave_usum63(unsigned int v) {
   return v;
 }
 
+#ifdef SLAMHIP_AUDIT
+// Diagnostic build only (-DSLAMHIP_AUDIT, tools/audit_certificate.py): every pixel that the cheap projection decides
+// (a whole rectangle at once, or pixel by pixel) is decided a second time with the reference-order functions of
+// geom_device.h.   [0] pixels inside the image   [1] decided by the cheap form   [2] left to the exact form
+//                  [3] "inside the window" differs (pixels)                      [6] "kept by _point_cloud" differs
+__device__ unsigned long long g_audit_ovl[8];
+__device__ __forceinline__ void audit_ovl_add(int i, unsigned long long n) {
+  if (n != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) atomicAdd(&g_audit_ovl[i], n);
+}
+#endif
+
 // A workgroup is a tile of OVL_TILE_W columns x 4 OVL_RPW rows, a wave a rectangle of OVL_TILE_W x OVL_RPW, a lane two
 // neighbouring image columns: a row of the lane is one 32-bit register {depth of column c | depth of column c + 1 << 16},
 // read with one 4-byte load where the plane allows it, and the statistics of the whole-rectangle decision run on the
@@ -238,6 +249,40 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
     }
   }
 
+#ifdef SLAMHIP_AUDIT
+  // the exact decision of one pixel (raw depth as masked above: pixels outside the image and the principal
+  // point's row / column hold 0)
+  auto audit_exact = [&](int row, int cole, unsigned int draw, bool& v0, bool& inb) {
+    double x, y, z, x2, y2, z2, u, v;
+    backproject_px(a.cam, cole, row, draw, x, y, z);
+    v0 = (x != 0.0) & (y != 0.0) & (z != 0.0);
+    transform_px(p, x, y, z, x2, y2, z2);
+    project_px(a.cam, x2, y2, z2, u, v);
+    inb = v0 && in_window(u, v, 2.0 * a.half_u, 2.0 * a.half_v);
+  };
+  {
+    unsigned long long n_img = 0, e_valid0 = 0, e_inb = 0, n_v0diff = 0;
+    for (int r = 0; r < RPW; ++r)
+      for (int e = 0; e < 2; ++e) {
+        const bool inside = row0 + r < H && col + e < W;
+        const unsigned int draw = e ? (a_d[r] >> 16) : (a_d[r] & 0xffffu);
+        const unsigned int raw = inside ? d1b[(long long)(row0 + r) * W + col + e] : 0u;   // unmasked
+        bool v0 = false, inb = false;
+        if (inside) audit_exact(row0 + r, col + e, raw, v0, inb);
+        n_img += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(inside));
+        e_valid0 += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(v0));
+        e_inb += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(inb));
+        n_v0diff += (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(inside && (v0 != (draw != 0u))));
+      }
+    audit_ovl_add(0, n_img);
+    audit_ovl_add(6, n_v0diff);
+    if (whole) {
+      audit_ovl_add(1, n_img);
+      audit_ovl_add(3, (e_valid0 > n_valid0 ? e_valid0 - n_valid0 : n_valid0 - e_valid0) +
+                           (e_inb > n_inb ? e_inb - n_inb : n_inb - e_inb));
+    }
+  }
+#endif
   if (whole) {
     // decided above
   } else if (cert_u) {
@@ -263,6 +308,16 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
         const unsigned long long m_out = m_z & (__builtin_amdgcn_ballot_w64(du > pc.out_u) | __builtin_amdgcn_ballot_w64(dv > pc.out_v));
         n_valid0 += (unsigned int)__popcll(m_in | m_out);
         n_inb += (unsigned int)__popcll(m_in);
+#ifdef SLAMHIP_AUDIT
+        {
+          bool v0 = false, inb = false;
+          if (row0 + r < H && col + e < W) audit_exact(row0 + r, col + e, draw, v0, inb);
+          const unsigned long long m_e = __builtin_amdgcn_ballot_w64(inb);
+          audit_ovl_add(1, (unsigned long long)__popcll(m_in | m_out));
+          audit_ovl_add(2, (unsigned long long)__popcll(m_valid0 & ~(m_in | m_out)));
+          audit_ovl_add(3, (unsigned long long)__popcll((m_in & ~m_e) | (m_out & m_e)));
+        }
+#endif
         const unsigned long long m_rest = m_valid0 & ~(m_in | m_out);   // near a border, behind the camera, non-finite
         if (m_rest != 0ull) {
           const unsigned int bit = __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
@@ -273,6 +328,11 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
     }
   } else {
     // no certificate (constants out of range, a degenerate pose): every pixel in the image
+#ifdef SLAMHIP_AUDIT
+    for (int r = 0; r < RPW; ++r)
+      for (int e = 0; e < 2; ++e)
+        audit_ovl_add(2, (unsigned long long)__popcll(__builtin_amdgcn_ballot_w64(row0 + r < H && col + e < W)));
+#endif
     const int n_in = min(max(H - row0, 0), RPW);
     const unsigned int rows_in = (1u << n_in) - 1u;     // RPW < 32
     rest0 = col < W ? rows_in : 0u;
@@ -397,3 +457,16 @@ extern "C" int slamhip_overlap_fused_ws(const uint16_t* depth, const double* rel
                   slamhip_overlap_fused_workspace_bytes(B));
   return launch_overlap_fused(depth, rel4x4, K, factor, dim_u, dim_v, B, H, W, counts, (unsigned int*)workspace, stream);
 }
+
+#ifdef SLAMHIP_AUDIT
+// audit build only: copies the eight counters to the host (after draining the device) and optionally clears them
+extern "C" int slamhip_audit_ovl_read(unsigned long long out[8], int reset) {
+  SLAMHIP_HIP(hipDeviceSynchronize());
+  SLAMHIP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_audit_ovl), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SLAMHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_audit_ovl), z, sizeof(z)));
+  }
+  return SLAMHIP_OK;
+}
+#endif

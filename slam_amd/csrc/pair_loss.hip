@@ -80,6 +80,20 @@ struct PairAcc {
 };
 static_assert(sizeof(PairAcc) == 128, "PairAcc must stay 128 bytes");
 
+#ifdef SLAMHIP_AUDIT
+// Diagnostic build only (-DSLAMHIP_AUDIT, tools/audit_certificate.py): every pixel that phase 1 certifies is
+// projected a second time with the reference-order functions of geom_device.h, and every decision phase 1 takes
+// for it is compared with the exact one.
+//   [0] pixels inside the image            [1] pixels phase 1 certified       [2] pixels left to phase 2
+//   [3] certified: "inside [0,W]x[0,H]" differs   [4] certified: "taps exist" differs
+//   [5] certified with taps: floor(u) or floor(v) differs           [6] "x, y, z all non-zero" differs
+__device__ unsigned long long g_audit[8];
+__device__ __forceinline__ void audit_add(int i, unsigned long long m) {
+  if (m != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
+    atomicAdd(&g_audit[i], (unsigned long long)__popcll(m));
+}
+#endif
+
 struct FusedArgs {   // everything but the pointers (those are __restrict__ kernel parameters of their own)
   Cam cam;
   // host-rounded quotients used by phase 1 only (any rounding is covered by the bound)
@@ -716,6 +730,31 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         asm("" : "+v"(idx));   // keeps the "* 8" of the cell size a shift: the reads are then known to be 8-byte aligned
         // (a select, not a masked read: reading under the lane mask saves the select and is 0.8 us slower per
         // launch for its two extra scalar instructions and the block boundary)
+#ifdef SLAMHIP_AUDIT
+        {
+          const int row = row0 + r;
+          double xe, ye, ze, x2e, y2e, z2e, ue, ve;
+          backproject_px(cam, col, row, draw, xe, ye, ze);
+          const bool v0e = (xe != 0.0) & (ye != 0.0) & (ze != 0.0);
+          transform_px(p, xe, ye, ze, x2e, y2e, z2e);
+          project_px(cam, x2e, y2e, z2e, ue, ve);
+          const bool inside = ((rows_in >> r) & 1u) && col < W;
+          const bool inb_e = v0e && in_window(ue, ve, (double)W, (double)H);
+          const bool wv_e = v0e && in_window(ue, ve, (double)(W - 1), (double)(H - 1)) && (z2e > 0.0);
+          const unsigned int iu_f = du + (unsigned int)wx0, iv_f = dv + (unsigned int)wy0;
+          const bool inb_f = iu_f < (unsigned int)W && iv_f < (unsigned int)H;
+          const bool wv_f = inb_f && iu_f + 1u < (unsigned int)W && iv_f + 1u < (unsigned int)H;
+          const unsigned long long m_in = __builtin_amdgcn_ballot_w64(inside);
+          audit_add(0, m_in);
+          audit_add(1, m_cert & m_in);
+          audit_add(2, m_in & m_valid0 & ~m_cert);
+          audit_add(3, m_cert & m_in & __builtin_amdgcn_ballot_w64(inb_f != inb_e));
+          audit_add(4, m_cert & m_in & __builtin_amdgcn_ballot_w64(wv_f != wv_e));
+          audit_add(5, m_cert & m_in & __builtin_amdgcn_ballot_w64(
+                           wv_e && ((int)iu_f != (int)floor(ue) || (int)iv_f != (int)floor(ve))));
+          audit_add(6, m_in & (m_valid0 ^ __builtin_amdgcn_ballot_w64(v0e && inside)));
+        }
+#endif
         o.t = read_cells(win, __builtin_amdgcn_inverse_ballot_w64(o.m_fast) ? idx : 0u);
         n_fast += (unsigned int)__popcll(o.m_fast);   // these pixels count for all three masks (added at the end)
         const unsigned long long m_other = m_valid0 & ~o.m_fast;
@@ -758,6 +797,13 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     } else {
       // no certificate (constants out of range, a degenerate pose) or no window: every pixel in the image
       rest_bits = __builtin_amdgcn_inverse_ballot_w64(col_in) ? rows_in : 0u;
+#ifdef SLAMHIP_AUDIT
+      for (int r = 0; r < RPW; ++r) {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(((rest_bits >> r) & 1u) != 0u);
+        audit_add(0, m);
+        audit_add(2, m);
+      }
+#endif
     }
 
     SLAMHIP_STAMP(8);   // phase 1 done
@@ -1100,5 +1146,18 @@ int slamhip_pair_loss_fused_static(const uint16_t* depth1, const uint8_t* rgb1, 
   return launch_pair_loss("pair_loss_fused_static", depth1, rgb1, depth2, rgb2, rel4x4, K, factor, B, k, H, W,
                           sums, counts, ptr, s);
 }
+
+#ifdef SLAMHIP_AUDIT
+// audit build only: copies the eight counters to the host (after draining the device) and optionally clears them
+int slamhip_audit_read(unsigned long long out[8], int reset) {
+  SLAMHIP_HIP(hipDeviceSynchronize());
+  SLAMHIP_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_audit), 8 * sizeof(unsigned long long)));
+  if (reset) {
+    const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    SLAMHIP_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_audit), z, sizeof(z)));
+  }
+  return SLAMHIP_OK;
+}
+#endif
 
 }  // extern "C"

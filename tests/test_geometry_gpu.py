@@ -479,3 +479,64 @@ def test_near_pixels_under_a_small_translation_project_just_above_the_image(fp):
     for b, (r, z) in enumerate(cases):
         assert -1 < v[b, r, W - 1] < 0 and W - 1 <= u[b, r, W - 1] < W
     _check_fused(fp, d1, c1, d2, c2, rel, K, 1.0)
+
+
+def test_decision_boundaries_adversarial_under_rotation(fp):
+    """One target pixel per pair whose projection under a ROTATION of 1 .. 35 degrees (plus translation) lies within
+    1e-12 .. 1e-6 of a decision of the reference - the borders 0, W-1, W / 0, H-1, H (test_import.py:174 and the tap
+    rule) or an interior integer (the floor that picks the taps): the translation is solved for, then refined on the
+    oracle's own float64 result, so that the target is met in the reference's arithmetic.  The certificate's bound
+    depends on the rotation, the depth and the intrinsics; a cheap projection that certified such a pixel would move
+    a count.  Masks, pixel indices and counts bit for bit."""
+    H, W = 24, 40
+    rs = np.random.RandomState(21)
+    offs = [0.0, 1e-12, -1e-12, 1e-10, -1e-9, 1e-9, 1e-8, -1e-7, 1e-6, -1e-6]
+    for factor in (1.0, 5000.0):
+        for K in ((517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480), (70.3, 69.1, 19.5, 12.25)):
+            B = 48
+            d1 = rs.randint(2000, 60001, size=(B, H, W)).astype(np.uint16)
+            d1[rs.uniform(size=d1.shape) < 0.05] = 0
+            rel = np.tile(np.eye(4), (B, 1, 1, 1))
+            hit = 0
+            for b in range(B):
+                axis = rs.normal(size=3)
+                axis /= np.linalg.norm(axis)
+                ang = np.deg2rad(rs.uniform(1.0, 35.0))
+                Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+                R = np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+                c, r = int(rs.randint(2, W - 2)), int(rs.randint(2, H - 2))
+                D = int(rs.randint(2000, 60001))
+                d1[b, r, c] = D
+                z = D / factor
+                p = np.array([(c - K[2]) * z / K[0], (r - K[3]) * z / K[1], z])
+                u_t = float(rs.choice([0, W - 1, W, int(rs.randint(1, W - 1))])) + offs[b % len(offs)]
+                v_t = float(rs.choice([0, H - 1, H, int(rs.randint(1, H - 1))])) + offs[(b * 3 + 1) % len(offs)]
+                if b % 2:
+                    u_t = float(int(rs.randint(1, W - 1))) + 0.37      # one coordinate adversarial at a time
+                else:
+                    v_t = float(int(rs.randint(1, H - 1))) + 0.61
+                t = np.zeros(3)
+                t[2] = rs.uniform(-0.2, 0.2) * z
+                zp = p @ R[:, 2] + t[2]
+                if zp <= 0.1 * z:
+                    continue
+                t[0] = (u_t - K[2]) * zp / K[0] - p @ R[:, 0]
+                t[1] = (v_t - K[3]) * zp / K[1] - p @ R[:, 1]
+                T = np.eye(4)
+                T[:3, :3], T[:3, 3] = R, t
+                for _ in range(4):      # refine on the oracle's own result at the target pixel
+                    P = so.warp_pair(d1[b], np.zeros((H, W, 3), np.uint8), d1[b], np.zeros((H, W, 3), np.uint8), T, K, factor)
+                    u, v, d = P["uvd"][r, c]
+                    T[0, 3] += (u_t - u) * d / K[0]
+                    T[1, 3] += (v_t - v) * d / K[1]
+                P = so.warp_pair(d1[b], np.zeros((H, W, 3), np.uint8), d1[b], np.zeros((H, W, 3), np.uint8), T, K, factor)
+                u, v, _ = P["uvd"][r, c]
+                hit += int(abs(u - u_t) < 2e-9 and abs(v - v_t) < 2e-9)
+                rel[b, 0] = T
+            assert hit > 0.8 * B, hit      # the construction does what it says
+            d2 = rs.randint(2500, 25001, size=(B, 1, H, W)).astype(np.uint16)
+            d2[rs.uniform(size=d2.shape) < 0.1] = 0
+            c1 = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+            c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
+            _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
+            _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
