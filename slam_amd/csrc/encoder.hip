@@ -892,6 +892,145 @@ wgrad_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float
 }
 
 // ---------------------------------------------------------------------------
+// Filter gradient with 256 x 256 (ci x co) tiles for the wide layers (Cin, Cout multiples of 256): the operand
+// scheme of igemm256_bf16_kernel - both tiles of a K-step go from global memory straight into LDS by
+// global_load_lds_dwordx4, two LDS buffers, eight waves (2 x 4, 128 x 64 outputs each), 0.75 KB of fragment reads
+// per MFMA - with the pixels as the K dimension: a K-step is 64 consecutive pixels, X and dY stay pixel-major in LDS
+// ([64 pixels][256 channels], rows of 512 bytes) and the fragments are read transposed (ds_read_b64_tr_b16).
+// A workgroup owns one tap of one tile and one slice of the pixels.
+//   LDS image of a tile: a DMA wave-instruction writes 1 KiB = two pixel rows; the 16-byte chunk q of row R is
+//   stored at position q ^ ((R & 3) << 2) (the loader permutes which global chunk a lane fetches), so that the four
+//   pixel rows x 64 bytes that 32 lanes of a transposing read touch fall into four distinct 64-byte bank groups.
+//   Pixels past the slice and taps outside the image fetch a line of zeros.
+// Pixel coordinates: row index q = p / W and q mod H by multiplication with 32-bit reciprocals (exact while
+// P * W < 2^32, checked by the caller).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(512)
+wgrad256_bf16_kernel(const bf16* __restrict__ X, const bf16* __restrict__ dY, float* __restrict__ dW, int P, int Cin,
+                     int Cout, int H, int W, int splitk, int total_work, unsigned int magic_w, unsigned int magic_h,
+                     long long det_stride) {
+  constexpr int TILE_BYTES = 64 * 512;                          // one operand tile of one K-step
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * TILE_BYTES];   // [buffer][X | dY]
+
+  const int per_xcd = (total_work + 7) >> 3;
+  const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (work >= total_work) return;
+  const int ci_tiles = Cin >> 8, co_tiles = Cout >> 8, jobs = 9 * ci_tiles * co_tiles;
+  const int slice = work / jobs;
+  int rest = work - slice * jobs;
+  const int tap = rest / (ci_tiles * co_tiles);
+  rest -= tap * ci_tiles * co_tiles;
+  const int ci0 = (rest / co_tiles) << 8, co0 = (rest % co_tiles) << 8;
+  const int dy = tap / 3 - 1, dx = tap % 3 - 1;
+  const int chunk = (((P + splitk - 1) / splitk) + 63) & ~63;   // slices are multiples of 64 pixels
+  const int p_begin = slice * chunk, p_end = min(P, p_begin + chunk);
+  const int ksteps = (p_end - p_begin + 63) >> 6;               // >= 1 (the caller drops empty slices)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+
+  // loader: piece j (0..3) of this wave covers the pixel rows r = (wave * 4 + j) * 2 + (lane >> 5) of the K-step;
+  // a lane sits at position lane & 31 and fetches global chunk position ^ ((r & 3) << 2)
+  int l_row[4], l_chunk[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    l_row[j] = (wave * 4 + j) * 2 + (lane >> 5);
+    l_chunk[j] = (lane & 31) ^ ((l_row[j] & 3) << 2);
+  }
+  const bf16* const x_base = X + ci0;
+  const bf16* const y_base = dY + co0;
+  const bf16* const zero_src = reinterpret_cast<const bf16*>(g_zero_line);
+  const long long tap_off = (long long)(dy * W + dx) * Cin;
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  // request the tiles of K-step s into buffer buf
+#define SLAMHIP_WG256_ISSUE(buf, s_)                                                                  \
+  {                                                                                                   \
+    unsigned char* x_dst = lds + (buf) * 2 * TILE_BYTES + wave * 4096;                                \
+    unsigned char* y_dst = x_dst + TILE_BYTES;                                                        \
+    const int pk = p_begin + ((s_) << 6);                                                             \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                   \
+      const int pp = pk + l_row[j];                                                                   \
+      const bool in_slice = pp < p_end;                                                               \
+      const unsigned int q = __umulhi((unsigned int)pp, magic_w);      /* image row over the batch */ \
+      const int x = pp - (int)q * W;                                                                  \
+      const int y = (int)q - (int)__umulhi(q, magic_h) * H;                                           \
+      const bool ok = in_slice && (unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W; \
+      const bf16* xs = ok ? x_base + (long long)pp * Cin + tap_off + l_chunk[j] * 8 : zero_src;       \
+      const bf16* ys = in_slice ? y_base + (long long)pp * Cout + l_chunk[j] * 8 : zero_src;          \
+      __builtin_amdgcn_global_load_lds((global_void_ptr)xs, (lds_void_ptr)(x_dst + j * 1024), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((global_void_ptr)ys, (lds_void_ptr)(y_dst + j * 1024), 16, 0, 0); \
+    }                                                                                                 \
+  }
+
+  // transposing fragment read from a swizzled tile: 16 pixels k0 .. k0 + 15 x 32 channels mbase ...
+  auto frag = [&](const unsigned char* tile, int k0, int mbase) -> bf16x8 {
+    // lanes 16g..16g+15: block of 4 pixel rows x 16 channels; lane 4q+p gives row q, channels 4p..4p+3
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p4 = i & 3, h = g >> 1;
+    const int c = mbase + (g & 1) * 16 + 4 * p4;                 // first of the lane's four channels
+    const int R0 = k0 + 8 * h + q, R1 = R0 + 4;                  // (R0 & 3) == (R1 & 3) == q: one swizzle for both
+    const int off = (((c >> 3) ^ (q << 2)) << 4) + ((c & 7) << 1);
+    const short4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(tile + R0 * 512 + off));
+    const short4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((short4_t __attribute__((address_space(3)))*)(tile + R1 * 512 + off));
+    bf16x8 f;
+    const bf16x4 l4 = __builtin_bit_cast(bf16x4, lo), h4 = __builtin_bit_cast(bf16x4, hi);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f[j] = l4[j]; f[4 + j] = h4[j]; }
+    return f;
+  };
+
+  // One barrier per K-step: the next step's tiles are requested, this step's fragments read and multiplied, then the
+  // wave waits for its own DMA loads and the barrier hands the buffers over.  (The two-phase schedule of
+  // igemm256_bf16_kernel, wave rows half a phase apart, was measured here too: 4.5 % faster at 56 x 56 x 256 x 256,
+  // 2-3 % slower on the three 28 x 28 and 14 x 14 shapes.)
+  SLAMHIP_WG256_ISSUE(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int s = 0; s < ksteps; ++s) {
+    const unsigned char* x_tile = lds + (s & 1) * 2 * TILE_BYTES;
+    const unsigned char* y_tile = x_tile + TILE_BYTES;
+    if (s + 1 < ksteps) SLAMHIP_WG256_ISSUE((s + 1) & 1, s + 1);   // in flight while the matrix cores work
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 16) {
+      bf16x8 af[4], bfr[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = frag(x_tile, kk, wm * 128 + i * 32);      // A[m = ci][k = pixel]
+#pragma unroll
+      for (int j = 0; j < 2; ++j) bfr[j] = frag(y_tile, kk, wn * 64 + j * 32);      // B[k = pixel][n = co]
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    // the next step's tiles have landed (this wave's DMA) and every wave is done reading this step's buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+#undef SLAMHIP_WG256_ISSUE
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const int co = co0 + wn * 64 + j * 32 + (lane & 31);
+        float* dst = &dW[((long long)tap * Cin + ci) * Cout + co];
+        if (splitk == 1) *dst = acc[i][j][r];
+        else if (det_stride) dst[slice * det_stride] = acc[i][j][r];   // fixed-order mode: this slice's own slot
+        else atomicAdd(dst, acc[i][j][r]);
+      }
+}
+
+// ---------------------------------------------------------------------------
 // Filter gradient of the layers with wide images and few channels: the per-tap
 // kernel above reads X and dY nine times from L2 and is bound by that.  Here a workgroup owns
 // one filter ROW (dy fixed, dx = -1, 0, +1) of a 64 x 64 (ci x co) tile: a K-step is a segment
@@ -2472,6 +2611,43 @@ int slamhip_wgrad_bf16(const void* x, const void* dy, float* dw, int B, int H, i
   hipStream_t s = (hipStream_t)stream;
   const long long P = (long long)B * H * W;
   SLAMHIP_REQUIRE(P <= 0x7fffffffLL, SLAMHIP_E_SIZE, "wgrad: too many pixels");
+  // wide layers: 256 x 256 tiles with DMA-staged operands, one workgroup per compute unit and tap
+  // (SLAMHIP_WGRAD256 = 0 turns it off)
+  static const bool wgrad256 = [] { const char* e = getenv("SLAMHIP_WGRAD256"); return e ? atoi(e) != 0 : true; }();
+  if (wgrad256 && taps == 9 && Cin % 256 == 0 && Cout % 256 == 0 && P >= 64 * 64 && P * (long long)W < (1LL << 32) &&
+      W >= 2 && H >= 2) {
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+      return n;
+    }();
+    const long long jobs = 9LL * (Cin / 256) * (Cout / 256);
+    long long split = cus / jobs;                       // one round of one workgroup per compute unit
+    if (split > P / (64 * 8)) split = P / (64 * 8);     // at least eight K-steps per slice
+    if (split < 1) split = 1;
+    const long long chunk = ((P + split - 1) / split + 63) / 64 * 64;
+    split = (P + chunk - 1) / chunk;                    // no empty slice
+    const long long n_dw = 9LL * Cin * Cout;
+    float* part = nullptr;
+    if (split > 1) {
+      if (deterministic_mode()) {
+        part = det_scratch(sizeof(float) * (size_t)n_dw * split);
+        SLAMHIP_REQUIRE(part, SLAMHIP_E_HIP, "deterministic mode: no scratch memory");
+      } else {
+        SLAMHIP_HIP(clear_accumulator(dw, sizeof(float) * (size_t)n_dw, s));
+      }
+    }
+    const long long total = jobs * split;
+    const unsigned int magic_w = (unsigned int)(((1ULL << 32) + (unsigned long long)W - 1) / (unsigned long long)W);
+    const unsigned int magic_h = (unsigned int)(((1ULL << 32) + (unsigned long long)H - 1) / (unsigned long long)H);
+    hipLaunchKernelGGL(wgrad256_bf16_kernel, dim3((unsigned)((total + 7) / 8 * 8)), dim3(512), 0, s, (const bf16*)x,
+                       (const bf16*)dy, part ? part : dw, (int)P, Cin, Cout, H, W, (int)split, (int)total, magic_w,
+                       magic_h, part ? n_dw : 0LL);
+    SLAMHIP_HIP(hipGetLastError());
+    if (part) SLAMHIP_HIP(ordered_sum(part, dw, split, n_dw, s));
+    return SLAMHIP_OK;
+  }
   // up to 128 input channels on wide images: one workgroup per filter row and 64 x 64 tile (see the
   // kernel; 1037 -> 726 us at 224 x 224 x 64 x 64, 772 -> 649 us at 112 x 112 x 128 x 128, batch 128).
   // SLAMHIP_WGRAD_ROWS64 = 0 turns it off, n limits it to 64 n input channels.

@@ -94,8 +94,12 @@ def graphdet(out):
     torch.cuda.synchronize()
     replayed = make()
     step = replayed.capture_train_step(warmup=2)
-    for _ in range(steps):          # the host runs ahead: nothing waits for the GPU between the steps
+    reads = os.environ.get("WORKER_READS", "0") == "1"
+    for _ in range(steps):          # the host runs ahead: nothing waits for the GPU between the steps ...
         step()
+        if reads:                   # ... or reads and allocates in between, as a training loop's logging does
+            assert all(bool(torch.isfinite(t).all()) for t in list(replayed.grads.values()) + list(replayed.params.values()))
+            float(replayed.loss)
     torch.cuda.synchronize()
     np.savez(out, p_eager=eager.flat_params.cpu().numpy(), p_graph=replayed.flat_params.cpu().numpy(),
              l_eager=eager.loss.cpu().numpy(), l_graph=replayed.loss.cpu().numpy(),

@@ -19,7 +19,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FALLBACK_ENV = {"SLAMHIP_IGEMM256": "0", "SLAMHIP_IGEMM_ROW3": "0", "SLAMHIP_WGRAD_ROWS64": "0",
+FALLBACK_ENV = {"SLAMHIP_IGEMM256": "0", "SLAMHIP_IGEMM_ROW3": "0", "SLAMHIP_WGRAD_ROWS64": "0", "SLAMHIP_WGRAD256": "0",
                 "SLAMHIP_WGRAD_ROWGROUP": "0", "SLAM_FUSE_FIRST_BWD": "0", "SLAM_FIRST_RECOMPUTE": "0"}
 
 
@@ -92,13 +92,16 @@ def test_batch_128_fixed_order_sums_reproduce_bit_for_bit(tmp_path):
     assert _rel(d["loss"], a["loss"]) < 1e-2
 
 
-def test_graph_replays_back_to_back_equal_eager_steps_bit_for_bit(tmp_path):
-    """Twelve replayed training steps with no synchronisation in between and a learning rate that changes at every
-    step, against the same steps launched eagerly, under fixed-order sums: identical parameters.  (The step size of
-    a replay is device data written by a fill kernel ahead of it; a reused pinned host slot could be overwritten
-    by a host that runs ahead.)"""
+@pytest.mark.parametrize("reads", ["0", "1"])
+def test_graph_replays_back_to_back_equal_eager_steps_bit_for_bit(tmp_path, reads):
+    """Twelve replayed training steps with no synchronisation in between (reads = 0) or with device-to-host reads
+    and allocations between them (reads = 1), and a learning rate that changes at every step, against the same
+    steps launched eagerly, under fixed-order sums: identical parameters.  (The step size of a replay is device data
+    written by a fill kernel ahead of it; a reused pinned host slot could be overwritten by a host that runs ahead.
+    With memset nodes in the recorded graph, replays now and then read accumulators that had not been cleared: the
+    library clears with kernels.)"""
     assert torch.cuda.is_available(), "GPU tests need a GPU"
-    r = _worker("graphdet", str(tmp_path / "g.npz"), DET)
+    r = _worker("graphdet", str(tmp_path / "g.npz"), dict(DET, WORKER_READS=reads))
     assert list(r["steps"]) == [14, 14]
     assert np.isfinite(r["p_graph"]).all()
     assert np.array_equal(r["l_eager"], r["l_graph"])

@@ -7,10 +7,10 @@ export ENC_GRAPH=0 ENC_FWD=0 ENC_STEPS=${ENC_STEPS:-5}
 timeout -s KILL 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out.d" -- python3 tools/bench_encoder.py > "$out.log" 2>&1 || { echo "trace run failed"; tail -5 "$out.log"; exit 1; }
 f=$(find "$out.d" -name '*kernel_stats.csv' | head -1)
 cp "$f" "$out.stats.csv"
-python3 - "$out.stats.csv" $((ENC_STEPS + 4)) > "$out.top.txt" <<'PY'
+python3 - "$out.stats.csv" $((ENC_STEPS + 2)) > "$out.top.txt" <<'PY'
 import csv, sys, re
 rows = list(csv.DictReader(open(sys.argv[1])))
-steps = int(sys.argv[2])      # 2 eager warm-up steps + 2 more + the timed ones
+steps = int(sys.argv[2])      # 2 warm-up steps + the timed ones
 tot = 0.0
 out = []
 for r in rows:
