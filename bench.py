@@ -401,12 +401,20 @@ def main():
         # and committed together with the hash of the kernel source it was measured on; reported only when
         # both the workload and the source still match
         traffic, traffic_src = None, None
-        tr = counters_for(os.path.join(ROOT, "profiles", "r2_traffic_fused.json"),
-                          os.path.join(ROOT, "slam_amd", "csrc", "pair_loss.hip"))
+        kernel_src = os.path.join(ROOT, "slam_amd", "csrc", "pair_loss.hip")
+        tr = counters_for(os.path.join(ROOT, "profiles", "r3_traffic_fused.json"), kernel_src)
         if tr is not None and (B, k, H, W) == (64, 1, 480, 640) and a.factor == 1.0 and a.depth == "plane":
             traffic = tr["hbm_bytes_per_launch"]
-            traffic_src = ("profiles/r2_traffic_fused.json (rocprofv3 --pmc: L2 read requests by size, 32 n32 + 64 n64 + 128 n128 "
+            traffic_src = ("profiles/r3_traffic_fused.json (rocprofv3 --pmc: L2 read requests by size, 32 n32 + 64 n64 + 128 n128 "
                            "= FETCH_SIZE x %.2f, + WRITE_SIZE; kernel source %s)" % (tr.get("fetch_size_factor", 2.0), tr["source_sha256"][:12]))
+        else:   # the other measured workloads (k > 1 neighbours, 1280 x 960): tools/pmc_traffic_workloads.sh
+            wl = counters_for(os.path.join(ROOT, "profiles", "r3_traffic_workloads.json"), kernel_src)
+            for r in (wl or {}).get("workloads", []):
+                if ((r["batch"], r["neighbours"], r["height"], r["width"]) == (B, k, H, W) and r["factor"] == a.factor
+                        and r["depth"] == a.depth):
+                    traffic = r["hbm_bytes_per_launch"]
+                    traffic_src = ("profiles/r3_traffic_workloads.json (rocprofv3 --pmc: L2 read requests by size + WRITE_SIZE; "
+                                   "kernel source %s)" % wl["source_sha256"][:12])
         pairs = world * B * k * a.steps
         achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9
         line = {
