@@ -73,3 +73,60 @@ def test_replays_follow_eager_calls():
         np.testing.assert_allclose(got[0].cpu().numpy(), want[0].cpu().numpy(), rtol=1e-9)
         np.testing.assert_allclose(got[3].cpu().numpy(), want[3].cpu().numpy(), rtol=1e-6, atol=1e-5)
         np.testing.assert_allclose(got[4].cpu().numpy(), want[4].cpu().numpy(), rtol=1e-12)
+
+
+def test_google_net_layers_replay_like_eager_calls():
+    """Forward and backward of a small graph that uses every GoogLeNet layer kernel (strided 7x7, 5x5, 1x1, concat
+    slices, fan-out sums, SAME / VALID pools, LRN, fc heads; slam/network/google_net.py:14-215) recorded in a HIP
+    graph and replayed on new inputs: outputs and every parameter gradient as the eager calls give them (the
+    library clears the bias-gradient and filter-gradient accumulators with kernels: the recording holds kernel
+    nodes only)."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    from slam_amd.network.network import Network
+
+    class SmallNet(Network):
+        def setup(self):
+            (self.feed('data').conv(7, 7, 16, 2, 2, name='stem').max_pool(3, 3, 2, 2, name='pool1')
+             .lrn(2, 2e-05, 0.75, name='norm1').conv(1, 1, 24, 1, 1, name='reduce'))
+            self.feed('reduce').conv(1, 1, 8, 1, 1, name='b1')
+            self.feed('reduce').conv(1, 1, 16, 1, 1, name='b3r').conv(3, 3, 24, 1, 1, name='b3')
+            self.feed('reduce').conv(1, 1, 8, 1, 1, name='b5r').conv(5, 5, 16, 1, 1, name='b5')
+            self.feed('reduce').max_pool(3, 3, 1, 1, name='bp').conv(1, 1, 16, 1, 1, name='bpp')
+            self.feed('b1', 'b3', 'b5', 'bpp').concat(3, name='cat')
+            (self.feed('cat').max_pool(3, 3, 2, 2, name='pool2').avg_pool(3, 3, 1, 1, padding='VALID', name='gap')
+             .fc(24, relu=False, name='fc1').fc(7, relu=False, name='out_main'))
+
+    dev = torch.device("cuda")
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 45, 53, 3, generator=g).to(dev)
+    net = SmallNet({'data': x}, seed=1)
+    d_out = net.layers['out_main'].d_out
+
+    def body():
+        net.forward()
+        net.backward()
+
+    d_out.copy_(torch.randn(3, 7, generator=g).to(dev))
+    body()                       # eager once: every lazily made buffer exists before the recording
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        body()
+    for seed in (6, 7):
+        gg = torch.Generator().manual_seed(seed)
+        x.copy_(torch.randn(3, 45, 53, 3, generator=gg).to(dev))
+        d_out.copy_(torch.randn(3, 7, generator=gg).to(dev))
+        body()
+        torch.cuda.synchronize()
+        want_out = net.outputs()['out_main'].clone()
+        want_g = net.flat_grads.clone()
+        net.flat_grads.fill_(7.0)
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert float(want_g.abs().max()) > 0
+        np.testing.assert_allclose(net.outputs()['out_main'].cpu().numpy(), want_out.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        scale = float(want_g.abs().max())
+        np.testing.assert_allclose(net.flat_grads.cpu().numpy(), want_g.cpu().numpy(), rtol=1e-3, atol=1e-4 * scale)
