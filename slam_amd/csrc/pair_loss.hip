@@ -421,6 +421,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 #ifdef SLAMHIP_ABL_HALF_ANCHORS   // timing ablation only: a quarter of the anchor loads
         if (r & 3) { a_d[r] = 1000u + r; a_q[r].x = a_q[r].y = 0x10203040u; continue; }
 #endif
+#ifdef SLAMHIP_ABL_ARITH_ONLY     // timing ablation only: no global loads at all (with SLAMHIP_ABL_NO_STAGE)
+        { a_d[r] = 5000u + 3u * (unsigned int)r + (unsigned int)lane; a_q[r].x = 0x10203040u + (unsigned int)lane; a_q[r].y = 0x50607080u; continue; }
+#endif
         a_d[r] = *reinterpret_cast<const uint16_t*>(drow + d_off);
         a_q[r] = *reinterpret_cast<const Dword2*>(crow + La);
       }
@@ -674,7 +677,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     asm volatile("" : "+v"(colq));
     const unsigned long long col_in = __builtin_amdgcn_ballot_w64(colq < W);
     const unsigned long long col_nz = __builtin_amdgcn_ballot_w64(colq < W && colq != a.cx_col);
-#ifdef SLAMHIP_ABL_NO_PHASE1     // timing ablation only: results are wrong
+#if defined(SLAMHIP_ABL_NO_PHASE1) || defined(SLAMHIP_ABL_LOADS_ONLY)   // timing ablation only: results are wrong
     if (false) {
 #else
     if (cert_u && nrows > 0) {
@@ -808,6 +811,17 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
 
     SLAMHIP_STAMP(8);   // phase 1 done
     // ---- phase 2: the reference's exact operation order for the pixels phase 1 left ----
+#ifdef SLAMHIP_ABL_LOADS_ONLY   // timing ablation only: every load and the staging, no projection, blend or sums
+    {
+      unsigned int chk = 0u;     // the anchors and one staged cell per lane stay alive in a store that never happens
+#pragma unroll
+      for (int r = 0; r < RPW; ++r) chk ^= a_d[r] ^ a_q[r].x ^ a_q[r].y;
+      const uint2 c0 = win[(lane * 7 + wave) % (WIN_PITCH * WIN_ROWS)];
+      chk ^= c0.x ^ c0.y;
+      if (chk == 0x9e3779b9u) counts[0] = chk;
+      rest_bits = 0u;
+    }
+#endif
 #ifdef SLAMHIP_ABL_NO_PHASE2   // timing ablation only: results are wrong
     rest_bits = 0u;
 #endif
