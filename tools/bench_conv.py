@@ -12,9 +12,12 @@ B, H, W, C, N = [int(v) for v in os.environ.get("CONV", "128,28,28,512,512").spl
 reps = int(os.environ.get("REPS", 20))
 which = os.environ.get("WHICH", "fwd,dgrad,wgrad").split(",")
 bf = dict(dtype=torch.bfloat16, device="cuda")
-x = torch.randn(B, H, W, C, **bf)
-dy = torch.randn(B, H, W, N, **bf)
-w = 0.05 * torch.randn(3, 3, C, N, device="cuda")
+if os.environ.get("ZERO", "0") == "1":      # all-zero operands: the same instructions at a fraction of the switching power
+    x, dy, w = torch.zeros(B, H, W, C, **bf), torch.zeros(B, H, W, N, **bf), torch.zeros(3, 3, C, N, device="cuda")
+else:
+    x = torch.randn(B, H, W, C, **bf)
+    dy = torch.randn(B, H, W, N, **bf)
+    w = 0.05 * torch.randn(3, 3, C, N, device="cuda")
 w_fwd, w_dg = torch.empty(N, 9 * C, **bf), torch.empty(C, 9 * N, **bf)
 ops.conv_weight_layouts(w, w_fwd, w_dg)
 out, dx = torch.empty(B, H, W, N, **bf), torch.empty(B, H, W, C, **bf)
