@@ -16,6 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def _spawn(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["SLAMHIP_DETERMINISTIC"] = "1"      # sums in a fixed order: what is left is the arithmetic, not the atomics' order
     return subprocess.Popen([sys.executable, os.path.join(HERE, "sync_bn_worker.py")] + [str(a) for a in args], env=env,
                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
 
@@ -74,6 +75,10 @@ def test_two_ranks_with_shared_statistics_match_one_process_on_the_whole_batch(t
         assert np.isfinite(sync[0][key]).all()
         np.testing.assert_array_equal(sync[0][key], sync[1][key])
         e_s, e_l = _rel(sync[0][key], full[key]), _rel(local[0][key], full[key])
-        # (measured 6e-3 for the output layer and 0.2-0.25 for the first layer - the distance two runs of one process
-        # keep as well - against 0.12 and 1.0 with per-rank statistics)
+        # (measured 1.1e-2 for the output layer and 0.30 for the first layer, against 0.12 and 1.0 with per-rank
+        # statistics.  The sums run in a fixed order here, so the 0.30 is no atomics' order: the mean of two half
+        # sums and the whole sum differ in the last bit, that moves bfloat16 roundings of the activations, and twelve
+        # normalised layers over eight images amplify it.  The exchange itself is checked to 1e-2 on one layer (bfloat16
+        # outputs), where nothing amplifies:
+        # test_encoder_gpu.py::test_batch_norm_backward_in_two_phases_over_two_shards_matches_the_whole_batch.)
         assert e_s < 0.5 and e_s < 0.5 * e_l, (key, e_s, e_l)
