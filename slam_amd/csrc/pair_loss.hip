@@ -42,8 +42,9 @@ namespace slamhip {
 //   B  all waves stage that window into LDS as 8-byte cells {R | G << 16, B | raw depth << 16}
 //      (colour bytes read as binary16 subnormals) with 16-byte / 8-byte global loads;
 //   C  phase 1 and phase 2 above; a tap outside the window (large parallax, a window
-//      cut at WIN_PITCH x WIN_ROWS) is gathered straight from global memory in phase 2,
-//      so the prediction never affects results.
+//      cut at WIN_PITCH x WIN_ROWS) is gathered straight from global memory - with the
+//      certified coordinates of phase 1 where the pixel has them (a tap pair in
+//      two vector loads), in phase 2 otherwise - so the prediction never affects results.
 // Predicates are 64-bit lane masks in scalar registers (one vector compare each,
 // combined and counted on the scalar unit).  Reduction: sums by DPP row reductions,
 // the four waves through LDS, then one float64 atomic instruction per workgroup (eight lanes:
@@ -260,6 +261,33 @@ __device__ __forceinline__ uint2 global_cell(const uint16_t* __restrict__ d2, co
                                              int x, int y) {
   const int o = y * W + x;
   return make_cell(c2[3 * o], c2[3 * o + 1], c2[3 * o + 2], d2[o]);
+}
+
+// The taps (x, y), (x + 1, y) of a pixel with x + 1 < W, straight from the neighbour's planes: exactly the ten bytes
+// that hold them (and the two after), in two loads at whatever alignment the pixel has (byte-aligned vector loads
+// are legal on gfx9 under the HSA runtime's memory configuration).
+struct __attribute__((packed, aligned(1))) U32u { unsigned int v; };
+struct __attribute__((packed, aligned(1))) U64u { unsigned int x, y; };
+// two raw depths; eight bytes of which bytes sh .. sh + 5 are R0 G0 B0 R1 G1 B1 (the load is pulled back by sh <= 2
+// bytes at the plane's last two pixels so that it stays inside the plane)
+struct TapPair { unsigned int dd, qx, qy, sh; };
+__device__ __forceinline__ TapPair load_tap_pair(const uint16_t* __restrict__ d2, const uint8_t* __restrict__ c2,
+                                                 unsigned int o, unsigned int plane_bytes) {
+  TapPair t;
+  t.dd = reinterpret_cast<const U32u*>(reinterpret_cast<const char*>(d2) + (size_t)(2u * o))->v;
+  const unsigned int at = 3u * o, base = min(at, plane_bytes - 8u);
+  t.sh = at - base;
+  const U64u q = *reinterpret_cast<const U64u*>(reinterpret_cast<const char*>(c2) + (size_t)base);
+  t.qx = q.x; t.qy = q.y;
+  return t;
+}
+__device__ __forceinline__ void tap_pair_cells(const TapPair& t, uint2& left, uint2& right) {
+  const unsigned int ca = __builtin_amdgcn_alignbyte(t.qy, t.qx, t.sh);   // R0 G0 B0 R1
+  const unsigned int cb = t.qy >> (8u * t.sh);                            // G1 B1 . .
+  left.x = __builtin_amdgcn_perm(0u, ca, 0x0c010c00u);      // R0 | G0 << 16
+  left.y = __builtin_amdgcn_perm(t.dd, ca, 0x05040c02u);    // B0 | depth0 << 16
+  right.x = __builtin_amdgcn_perm(cb, ca, 0x0c040c03u);     // R1 | G1 << 16
+  right.y = __builtin_amdgcn_perm(t.dd, cb, 0x07060c01u);   // B1 | depth1 << 16
 }
 
 // Projection of one anchor pixel in float32, for window prediction only.
@@ -553,6 +581,19 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         if (!bad && bx1 >= bx0 && by1 >= by0 && a.stage_vec) {
           wx0 = bx0 & ~(CHUNK - 1);
           wy0 = by0;
+          if (bx1 + 1 - wx0 > WIN_PITCH || by1 + 1 - wy0 > WIN_ROWS) {
+            // The taps' box is larger than the window (parallax over a wide depth range).  Parallax goes with 1 / z,
+            // so equal steps of depth crowd together at the far end of the box: the window is laid over the
+            // projections of the tile at its farthest depth and reaches from there towards the near end.
+            const bool far_corner = (lane & 4) != 0;
+            const unsigned int fmn = oct_pk_min(far_corner ? (((unsigned int)min(lo_v, 0x7fff) << 16) | (unsigned int)min(lo_u, 0xffff)) : 0xffffffffu);
+            const unsigned int fmx = oct_pk_max(far_corner ? (((unsigned int)max(hi_v, 0) << 16) | (unsigned int)max(hi_u, 0)) : 0u);
+            const unsigned int smn = (unsigned int)__builtin_amdgcn_readfirstlane((int)fmn);
+            const unsigned int smx = (unsigned int)__builtin_amdgcn_readfirstlane((int)fmx);
+            const int fx0 = (int)(smn & 0xffffu), fy0 = (int)(smn >> 16), fx1 = (int)(smx & 0xffffu), fy1 = (int)(smx >> 16);
+            if (fx0 - bx0 > bx1 - fx1) wx0 = max(wx0, (fx1 + 1 - WIN_PITCH + (CHUNK - 1)) & ~(CHUNK - 1));
+            if (fy0 - by0 > by1 - fy1) wy0 = max(wy0, fy1 + 1 - WIN_ROWS);
+          }
           ncols = min(bx1 + 1 - wx0, WIN_PITCH);   // a larger box is cut: the rest goes the slow way
           nrows = min(by1 + 1 - wy0, WIN_ROWS);
           if (ncols < 2 || nrows < 2) ncols = nrows = 0;   // a tap needs two columns and two rows
@@ -656,7 +697,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     Acc acc = {0.f, 0.f, 0.0, 0.0};
     unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_fast = 0;
     unsigned int n_geo = 0u;       // pixels with four non-zero depth taps (counted from the lane masks)
-    unsigned int rest_bits = 0u;   // bit r: row r of this lane is left to phase 2
+    // bit r: row r of this lane is left to phase 2; bit 16 + r: certified, inside the image, taps outside the window
+    static_assert(RPW <= 16, "two bits per row in a 32-bit mask");
+    unsigned int rest_bits = 0u;
 
     PairConsts pc;
     if constexpr (K1) pc = s_pc;     // written by wave 1 ahead of the first barrier
@@ -706,12 +749,12 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         double Z;
         Cells t;
       };
-      auto project_row = [&](const int r) -> Row {
-        Row o;
-        const unsigned int draw = a_d[r];
+      // window-relative floor (du, dv), fractions and z' of one pixel from its raw depth and its row's A, B, C
+      auto coords = [](const unsigned int draw, const double Ar, const double Br, const double Cr, const double t0p,
+                       const double t1p, const double t2, const double cxw, const double cyw, unsigned int& du,
+                       unsigned int& dv, float& fu, float& fv, double& Zo) {
         const double z = (double)draw;
-        const double X = fma(z, A, t0p), Y = fma(z, Bq, t1p), Z = fma(z, C, t2);
-        A += kAr; Bq += kBr; C += kCr;
+        const double X = fma(z, Ar, t0p), Y = fma(z, Br, t1p), Z = fma(z, Cr, t2);
         double rz = __builtin_amdgcn_rcp(Z);
         rz = fma(rz, fma(-Z, rz, 1.0), rz);
         const double uw = fma(X, rz, cxw), vw = fma(Y, rz, cyw);
@@ -719,10 +762,19 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         int tu, tv;
         asm("v_cvt_i32_f64 %0, %1" : "=v"(tu) : "v"(uw));
         asm("v_cvt_i32_f64 %0, %1" : "=v"(tv) : "v"(vw));
-        o.fu = (float)__builtin_amdgcn_fract(uw);
-        o.fv = (float)__builtin_amdgcn_fract(vw);
+        fu = (float)__builtin_amdgcn_fract(uw);
+        fv = (float)__builtin_amdgcn_fract(vw);
+        Zo = Z;
+        du = (unsigned int)tu - 65537u; dv = (unsigned int)tv - 65537u;   // floor - window origin
+      };
+      auto project_row = [&](const int r) -> Row {
+        Row o;
+        const unsigned int draw = a_d[r];
+        unsigned int du, dv;
+        double Z;
+        coords(draw, A, Bq, C, t0p, t1p, t2, cxw, cyw, du, dv, o.fu, o.fv, Z);
         o.Z = Z;
-        const unsigned int du = (unsigned int)tu - 65537u, dv = (unsigned int)tv - 65537u;   // floor - window origin
+        A += kAr; Bq += kBr; C += kCr;
         unsigned long long m_valid0 = __builtin_amdgcn_ballot_w64(draw != 0u) & col_nz;
         if (!((rows_nz >> r) & 1u)) m_valid0 = 0ull;
         // certified: z' safely positive and both coordinates farther than the bound from every integer
@@ -775,8 +827,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
                                           __builtin_amdgcn_ballot_w64(iv + 1u < (unsigned int)H);
           n_valid0 += (unsigned int)__popcll(m_out & ~m_wv);
           n_inb += (unsigned int)__popcll(m_inb & ~m_wv);
-          const unsigned long long m_rest = (m_valid0 & ~m_cert) | m_wv;
-          if (m_rest != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_rest) ? (1u << r) : 0u;
+          const unsigned long long m_unc = m_valid0 & ~m_cert;
+          if (m_unc != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_unc) ? (1u << r) : 0u;
+          if (m_wv != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_wv) ? (0x10000u << r) : 0u;
         }
         return o;
       };
@@ -796,6 +849,78 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
         cur = nxt;
         __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead: more only lengthens live ranges
+      }
+      // ---- certified pixels inside the image whose taps the window does not hold (parallax beyond the window's
+      // reach): the same coordinates again - the same operations on the same values - and the four taps gathered
+      // from the neighbour's planes, a row ahead of their blend like the window reads above ----
+      if (__builtin_amdgcn_ballot_w64((rest_bits >> 16) != 0u) != 0ull) {
+        // (the per-column constants are fetched or made again: kept from phase 1 they would take twelve registers there)
+        asm volatile("" ::: "memory");
+        PairConsts pg;
+        if constexpr (K1) pg = s_pc;
+        else pg = pair_consts(p);
+        double A2 = fma(ucx, pg.kAc, fma(vcy0, pg.kAr, pg.kA0));
+        double B2 = fma(ucx, pg.kBc, fma(vcy0, pg.kBr, pg.kB0));
+        double C2 = fma(ucx, pg.kCc, fma(vcy0, pg.kCr, pg.kC0));
+        const double cxg = cam.cx - (double)(wx0 - 1) + WBIAS, cyg = cam.cy - (double)(wy0 - 1) + WBIAS;
+        struct Gather {
+          unsigned long long m;   // lanes that gather in this row
+          float fu, fv;
+          double Z;
+          unsigned int a_rgb;     // the anchor's colour bytes
+          TapPair top, bot;
+        };
+        const unsigned int o_lane = (unsigned int)row0 * (unsigned int)W + (unsigned int)colc;
+        const unsigned int plane_bytes = 3u * (unsigned int)H * (unsigned int)W;
+        // (the anchors' colours are read again - cache hits, next to their neighbours in the wave - instead of being
+        // kept from phase 1, where each row's colour registers are free once the row is blended; four bytes from the
+        // pixel's first, pulled back by one at the plane's last pixel)
+        auto gather_row = [&](const int r) -> Gather {
+          Gather g;
+          const bool need = (rest_bits >> (16 + r)) & 1u;
+          g.m = __builtin_amdgcn_ballot_w64(need);
+          g.fu = g.fv = 0.0f; g.Z = 0.0;
+          g.a_rgb = 0u;
+          g.top = g.bot = TapPair{0u, 0u, 0u, 0u};
+          if (g.m != 0ull) {
+            unsigned int du, dv;
+            coords(a_d[r], A2, B2, C2, pg.t0p, pg.t1p, pg.t2, cxg, cyg, du, dv, g.fu, g.fv, g.Z);
+            if (need) {
+              const unsigned int at = 3u * (o_lane + (unsigned int)r * (unsigned int)W), base = min(at, plane_bytes - 4u);
+              g.a_rgb = reinterpret_cast<const U32u*>(c1b + (size_t)base)->v;   // (shifted into place at its use)
+              const unsigned int o = (dv + (unsigned int)wy0) * (unsigned int)W + du + (unsigned int)wx0;
+              g.top = load_tap_pair(d2, c2, o, plane_bytes);
+              g.bot = load_tap_pair(d2, c2, o + (unsigned int)W, plane_bytes);
+            }
+          }
+          A2 += pg.kAr; B2 += pg.kBr; C2 += pg.kCr;
+          return g;
+        };
+        Gather gc = gather_row(0);
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+          Gather gn = gc;
+          if (r + 1 < RPW) gn = gather_row(r + 1);
+          if (gc.m != 0ull) {
+            Cells t;
+            tap_pair_cells(gc.top, t.a, t.b);
+            tap_pair_cells(gc.bot, t.c, t.e);
+            const unsigned long long m_geo = gc.m & __builtin_amdgcn_ballot_w64(taps_nonzero(t));
+            n_fast += (unsigned int)__popcll(gc.m);
+            n_geo += (unsigned int)__popcll(m_geo);
+            if (__builtin_amdgcn_inverse_ballot_w64(gc.m)) {
+              const unsigned int at = 3u * (o_lane + (unsigned int)r * (unsigned int)W);
+              const unsigned int rgb = gc.a_rgb >> (at + 4u > plane_bytes ? 8u : 0u);
+              const unsigned int a_rg = __builtin_amdgcn_perm(0u, rgb, 0x0c010c00u);
+              const unsigned int a_b = __builtin_amdgcn_perm(0u, rgb, 0x0c0c0c02u);
+              blend_accumulate<UNIT>(acc, __builtin_amdgcn_inverse_ballot_w64(m_geo), t, gc.fu, gc.fv, inv_factor_f,
+                                     a_rg, a_b, gc.Z);
+            }
+          }
+          gc = gn;
+          __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead
+        }
+        rest_bits &= 0xffffu;
       }
     } else {
       // no certificate (constants out of range, a degenerate pose) or no window: every pixel in the image
