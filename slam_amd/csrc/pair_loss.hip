@@ -88,6 +88,7 @@ static_assert(sizeof(PairAcc) == 128, "PairAcc must stay 128 bytes");
 //   [0] pixels inside the image            [1] pixels phase 1 certified       [2] pixels left to phase 2
 //   [3] certified: "inside [0,W]x[0,H]" differs   [4] certified: "taps exist" differs
 //   [5] certified with taps: floor(u) or floor(v) differs           [6] "x, y, z all non-zero" differs
+//   [7] certified pixels whose taps were gathered from outside the window (a subset of [1])
 __device__ unsigned long long g_audit[8];
 __device__ __forceinline__ void audit_add(int i, unsigned long long m) {
   if (m != 0ull && __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u)
@@ -902,6 +903,9 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
           Gather gn = gc;
           if (r + 1 < RPW) gn = gather_row(r + 1);
           if (gc.m != 0ull) {
+#ifdef SLAMHIP_AUDIT
+            audit_add(7, gc.m);
+#endif
             Cells t;
             tap_pair_cells(gc.top, t.a, t.b);
             tap_pair_cells(gc.bot, t.c, t.e);

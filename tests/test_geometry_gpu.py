@@ -540,3 +540,40 @@ def test_decision_boundaries_adversarial_under_rotation(fp):
             c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
             _check_warp(fp, d1, c1, d2, c2, rel, K, factor)
             _check_fused(fp, d1, c1, d2, c2, rel, K, factor)
+
+
+@pytest.mark.parametrize("direction", [+1, -1])
+def test_taps_gathered_at_the_end_of_the_neighbour_planes(fp, direction):
+    """Certified pixels whose taps lie outside the staged window are gathered with vector loads that reach past the
+    taps' own bytes; at the last pixels of a plane those loads are pulled back to stay inside it.  Few pixels carry
+    depth here, so that a single wrong tap or anchor colour moves the sums far beyond the tolerance: one row at 5 m
+    (it lays the window next to the tile) and one near row whose depths send every pixel to the same far column -
+    +1: taps (W - 2, H - 2) .. (W - 1, H - 1), the last pixel of the neighbour's planes; -1: anchors in the last
+    row up to the anchor planes' last pixel, moving up and left across the image."""
+    H, W, factor = 32, 320, 5000.0
+    K = (517.3 * W / 640, 516.5 * H / 480, 318.6 * W / 640, 255.3 * H / 480)
+    B = 3
+    rs = np.random.RandomState(11 + direction)
+    c1 = rs.randint(0, 256, size=(B, H, W, 3)).astype(np.uint8)
+    c2 = rs.randint(0, 256, size=(B, 1, H, W, 3)).astype(np.uint8)
+    d2 = rs.randint(2500, 25001, size=(B, 1, H, W)).astype(np.uint16)
+    d1 = np.zeros((B, H, W), np.uint16)
+    rel = np.tile(np.eye(4), (B, 1, 1, 1))
+    if direction > 0:
+        tx = 0.5
+        rel[:, :, 0, 3], rel[:, :, 1, 3] = tx, 0.004             # (v = row + 0.2 .. 0.35: no integer, so certified)
+        cols = np.arange(0, 128)
+        d1[:, 20, cols] = 25000
+        z = K[0] * tx / ((W - 1.5) - cols)                      # u = col + fx tx / z = W - 1.5
+        d1[:, H - 2, cols] = np.round(z * factor).astype(np.uint16)
+    else:
+        tx, ty = -0.5, -0.1
+        rel[:, :, 0, 3], rel[:, :, 1, 3] = tx, ty
+        cols = np.arange(W - 64, W)
+        d1[:, 20, cols] = 25000
+        d1[:, H - 1, cols] = 2250 + 40 * np.arange(64)           # 0.45 .. 0.95 m: some 130 .. 290 columns to the left
+    want_s, want_c = so.pair_loss(d1, c1, d2, c2, rel, K, factor)
+    assert want_c[..., 2].min() >= 64 + 30                       # the near rows do warp (the far row always does)
+    sums, counts = fp.pair_loss(_dev(d1), _dev(c1), _dev(d2), _dev(c2), _dev(rel), K, factor)
+    assert np.array_equal(_u32(counts), want_c.astype(np.int64))
+    np.testing.assert_allclose(sums.cpu().numpy(), want_s, rtol=2e-5, atol=1e-6)

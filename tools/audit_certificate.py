@@ -20,7 +20,7 @@ from slam_amd import capi                       # noqa: E402
 from slam_amd import frame_pairs as fp          # noqa: E402
 
 NAMES = ["pixels", "decided_by_cheap_form", "left_to_exact_form", "inside_window_differs", "taps_exist_differs",
-         "floor_differs", "kept_by_point_cloud_differs", "unused"]
+         "floor_differs", "kept_by_point_cloud_differs", "taps_gathered_outside_window"]
 
 
 def rotation(axis, deg):
@@ -90,7 +90,7 @@ def main():
                         lib.slamhip_audit_ovl_read(buf, 1)
                         tot_o += np.array(list(buf), np.uint64)
                         rows.append({"size": "%dx%d" % (W, H), "intrinsics": "%s x%g" % (iname, scale), "factor": factor,
-                                     "depth": kind, "pair_loss_fused": dict(zip(NAMES[:7], [int(v) for v in tot[:7]])),
+                                     "depth": kind, "pair_loss_fused": dict(zip(NAMES[:8], [int(v) for v in tot[:8]])),
                                      "overlap_fused": {NAMES[i]: int(tot_o[i]) for i in (0, 1, 2, 3, 6)}})
                         print(rows[-1], flush=True)
     def total(key, name):
@@ -101,6 +101,8 @@ def main():
         mism = {n: total(key, n) for n in rows[0][key] if n.endswith("differs")}
         summary[key] = {"pixels": px, "decided_by_cheap_form": dec, "left_to_exact_form": rest,
                         "exact_fraction": rest / max(px, 1), "mismatches": mism, "mismatches_total": int(sum(mism.values()))}
+        if key == "pair_loss_fused":
+            summary[key]["taps_gathered_outside_window"] = total(key, "taps_gathered_outside_window")
     json.dump({"what": "in-kernel audit of the certified cheap projection against the reference-order projection",
                "sweep": "rotation 0/0.5/3/10/20/40 deg x translation 0/0.05/0.5/2/5 m x depth uniform 1..65535 / near 1..299 / "
                         "plane / constant x factor 1 / 5000 x fr1, fr2, fr3 (and doubled) x 640x480, 1280x960; %d pairs per point" % B,
