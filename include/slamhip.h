@@ -139,7 +139,8 @@ int slamhip_overlap_fused(const uint16_t* depth, const double* rel4x4, const dou
  * slamhip_overlap_fused_workspace_bytes, 16-byte aligned) which the caller zero-fills once (slamhip_zero_fill);
  * every call leaves it zero-filled again - the workgroup that finishes a frame last moves the totals to `counts` and
  * clears the record - so there is no clearing kernel.  Calls that share a workspace must not overlap; after a failed
- * or interrupted call zero-fill it again. */
+ * or interrupted call zero-fill it again.  A frame's two counts and its tickets share one 64-bit word: frames of more
+ * than some 2^25 pixels do not fit (SLAMHIP_E_SIZE; slamhip_overlap_fused has no such limit). */
 size_t slamhip_overlap_fused_workspace_bytes(int B);
 int slamhip_overlap_fused_ws(const uint16_t* depth, const double* rel4x4, const double K[4], double factor,
                              double dim_u, double dim_v, int B, int H, int W, uint32_t* counts, void* workspace,

@@ -43,6 +43,7 @@ struct OvlArgs {
   int cert_ok;             // the constants are mid-range: the cheap form may decide pixels
   int cx_col, cy_row;      // the column / row with col - cx == 0 / row - cy == 0, or -1
   int pair_loads;          // W is even and the plane 4-byte aligned: a lane reads its two columns in one load
+  int count_bits;          // with a workspace: bits per count in a frame's 64-bit record {kept, inside, tickets}
 };
 
 // Constants of the cheap projection that depend on the pair alone (wave-uniform).
@@ -368,28 +369,30 @@ overlap_fused_kernel(const OvlArgs a, const uint16_t* __restrict__ depth, const 
   // ---- the four waves through LDS, one atomic instruction per workgroup ----
   if (lane == 0) { s_cnt[wave][0] = n_valid0; s_cnt[wave][1] = n_inb; }
   __syncthreads();
+  if (acc && a.count_bits > 0) {
+    // Workspace record of the frame as ONE 64-bit word {kept | inside << n | tickets << 2 n}: a workgroup adds its
+    // two counts and its ticket with a single atomic instruction and learns from the value that comes back whether
+    // it was the last of the frame - then old + its own are the totals, which it moves to `counts`, and it leaves
+    // the record zero for the next call.  One round trip to the L2 per workgroup, no clearing kernel.
+    if (tid == 0) {
+      const unsigned int n = (unsigned int)a.count_bits;
+      const unsigned long long c0 = s_cnt[0][0] + s_cnt[1][0] + s_cnt[2][0] + s_cnt[3][0];
+      const unsigned long long c1 = s_cnt[0][1] + s_cnt[1][1] + s_cnt[2][1] + s_cnt[3][1];
+      const unsigned long long mine = c0 | (c1 << n) | (1ull << (2u * n));
+      unsigned long long* rec = reinterpret_cast<unsigned long long*>(acc + 4 * (long long)b);
+      const unsigned long long old = atomicAdd(rec, mine);
+      if ((old >> (2u * n)) == (unsigned long long)(gridDim.x * gridDim.y - 1u)) {
+        const unsigned long long tot = old + mine, mask = (1ull << n) - 1ull;
+        counts[2 * (long long)b] = (unsigned int)(tot & mask);
+        counts[2 * (long long)b + 1] = (unsigned int)((tot >> n) & mask);
+        atomicExch(rec, 0ull);
+      }
+    }
+    return;
+  }
   if (tid < 2) {
     const unsigned int c = s_cnt[0][tid] + s_cnt[1][tid] + s_cnt[2][tid] + s_cnt[3][tid];
-    if (acc) {
-      // the caller's zero-filled record {valid, inside, ticket, -} of this frame: the workgroup that draws the
-      // last ticket moves the totals to `counts` and leaves the record zero-filled for the next call - one
-      // launch, no clearing kernel
-      if (c) atomicAdd(&acc[4 * (long long)b + tid], c);
-    } else if (c) {
-      atomicAdd(&counts[2 * (long long)b + tid], c);
-    }
-  }
-  if (acc && wave == 0) {
-    // the two adds (lanes 0 and 1 of this wave) have been performed at the L2 before the ticket is drawn: the
-    // wave waits for their acknowledgement (stores and atomics without a result count in vmcnt on gfx9)
-    __builtin_amdgcn_s_waitcnt(0);
-    unsigned int t = 0;
-    if (lane == 0) t = atomicAdd(&acc[4 * (long long)b + 2], 1u);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t == gridDim.x * gridDim.y - 1u) {       // every other workgroup of the frame drew its ticket after its adds
-      if (lane < 2) counts[2 * (long long)b + lane] = atomicExch(&acc[4 * (long long)b + lane], 0u);
-      else if (lane == 2) atomicExch(&acc[4 * (long long)b + 2], 0u);
-    }
+    if (c) atomicAdd(&counts[2 * (long long)b + tid], c);
   }
 }
 
@@ -432,6 +435,15 @@ static int launch_overlap_fused(const uint16_t* depth, const double* rel4x4, con
   a.cx_col = int_index(K[2], W);
   a.cy_row = int_index(K[3], H);
   a.pair_loads = (W % 2 == 0) && W >= 2 && (reinterpret_cast<uintptr_t>(depth) % 4) == 0;
+  // bits for a count of up to H W pixels and for tiles_x tiles_y tickets: packed into one word when they fit
+  {
+    auto bits = [](unsigned long long v) { int n = 0; while (v) { ++n; v >>= 1; } return n; };
+    const int nb = bits((unsigned long long)H * W), tb = bits((unsigned long long)tiles_x * tiles_y);
+    a.count_bits = acc ? nb : 0;
+    SLAMHIP_REQUIRE(!acc || 2 * nb + tb <= 64, SLAMHIP_E_SIZE,
+                    "overlap_fused_ws: %d x %d frames need %d bits per workspace record (64 available); use slamhip_overlap_fused",
+                    W, H, 2 * nb + tb);
+  }
   // without a workspace the counters are cleared by a kernel on the stream (a call recorded in a HIP graph holds
   // kernel nodes only); with one the call is this launch alone
   if (!acc) clear_u32_async(counts, 2LL * B, s);

@@ -1114,13 +1114,13 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
   // reads less - the kernel is bound by vector instructions, and the k pairs of an anchor tile run back to
   // back on one XCD, so the repeated anchor reads come from its L2.  Measured per launch of 64 pairs:
   // k = 1: 76.5 us against 85.2 us; k = 4 (16 anchors): 71.6 us against 91.7 us.  Tuning builds (-DSLAMHIP_TUNING_TILES) hold the other
-  // tile shapes (SLAMHIP_TILE = 16x16, 16x8, 24x12, 32x16, 32x32) and the shared-anchor form
+  // tile shapes (SLAMHIP_TILE = 16x16, 16x8, 24x12, 32x16, 12x6, 20x10, 8x4) and the shared-anchor form
   // (SLAMHIP_SHARED_ANCHORS=1).
 #ifdef SLAMHIP_TUNING_TILES
   static const int tile_env = []() {
     const char* e = getenv("SLAMHIP_TILE");
     const std::string v = e ? e : "";
-    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x32" ? 4 : v == "32x16" ? 5 : v == "12x6" ? 6 :
+    return v == "16x16" ? 1 : v == "16x8" ? 2 : v == "24x12" ? 3 : v == "32x16" ? 5 : v == "12x6" ? 6 :
            v == "20x10" ? 7 : v == "8x4" ? 8 : 0;
   }();
   static const bool shared_env = []() { const char* e = getenv("SLAMHIP_SHARED_ANCHORS"); return e && atoi(e) != 0; }();
@@ -1191,7 +1191,6 @@ static int launch_pair_loss(const char* who, const uint16_t* depth1, const uint8
     switch (tile_cfg) {
       case 1: SLAMHIP_LAUNCH_FUSED(16, 16, true); break;
       case 2: SLAMHIP_LAUNCH_FUSED(16, 8, true); break;
-      case 4: SLAMHIP_LAUNCH_FUSED(32, 32, true); break;
       case 5: SLAMHIP_LAUNCH_FUSED(32, 16, true); break;
       case 6: SLAMHIP_LAUNCH_FUSED(12, 6, true); break;
       case 7: SLAMHIP_LAUNCH_FUSED(20, 10, true); break;

@@ -210,3 +210,8 @@ def test_argument_errors(fp):
     assert lib.slamhip_overlap_fused(None, a16, capi.K4([500, 500, 64, 12]), 1.0, 640.0, 480.0, 1, 4, 8, a16, None) < 0
     assert lib.slamhip_overlap_fused(a16, a16, capi.K4([500, 500, 64, 12]), 1.0, 640.0, 480.0, 70000, 4, 8, a16, None) < 0
     assert lib.slamhip_overlap_fused(None, None, capi.K4([500, 500, 64, 12]), 1.0, 640.0, 480.0, 0, 4, 8, None, None) == 0
+    # the one-launch entry keeps a frame's counts and tickets in one 64-bit word: 16384 x 16384 frames do not fit
+    # (rejected before anything is launched; the plain entry has no such limit)
+    K = capi.K4([500, 500, 64, 12])
+    assert lib.slamhip_overlap_fused_ws(a16, a16, K, 1.0, 640.0, 480.0, 1, 16384, 16384, a16, a16, 64, None) == -3
+    assert "bits per workspace record" in lib.slamhip_last_error().decode()

@@ -1,5 +1,6 @@
 #!/bin/bash
-# HBM bytes per launch of pair_loss_fused_kernel for workloads other than the default one (k > 1 neighbours, 1280x960):
+# HBM bytes per launch of pair_loss_fused_kernel for workloads other than the default one (k > 1 neighbours, 1280x960,
+# metric depth on a plane and as per-pixel noise, where taps are gathered from outside the LDS window):
 # two rocprofv3 --pmc passes each (L2 read requests by size; WRITE_SIZE) over tools/tune_fused.py, as
 # tools/pmc_traffic.sh does for the default workload (whose calibration of the request sizes applies here too).
 #   usage (on the GPU box): bash tools/pmc_traffic_workloads.sh gpurun_out/traffic_wl   -> <out>.json
@@ -10,7 +11,8 @@ export REPS=20
 SIZED="TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
 rm -rf "$out"; mkdir -p "$out"
 i=0
-for wl in "B=64 KN=1 SIZE=480x640" "B=32 KN=2 SIZE=480x640" "B=16 KN=4 SIZE=480x640" "B=16 KN=4 SIZE=960x1280" "B=16 KN=1 SIZE=960x1280"; do
+for wl in "B=64 KN=1 SIZE=480x640" "B=32 KN=2 SIZE=480x640" "B=16 KN=4 SIZE=480x640" "B=16 KN=4 SIZE=960x1280" "B=16 KN=1 SIZE=960x1280" \
+          "B=64 KN=1 SIZE=480x640 DEPTH=noise FACTOR=5000" "B=64 KN=1 SIZE=480x640 DEPTH=plane FACTOR=5000"; do
   i=$((i + 1))
   echo "$wl" > "$out/wl$i.txt"
   for pass in SIZED WRITE; do
@@ -39,7 +41,7 @@ for f in sorted(glob.glob(out + "/wl*.txt")):
     rd = 32.0 * mean(c["TCC_EA0_RDREQ_32B_sum"]) + 64.0 * mean(c["TCC_EA0_RDREQ_64B_sum"]) + 128.0 * mean(c["TCC_EA0_RDREQ_128B_sum"])
     wr = mean(w["WRITE_SIZE"]) * 1024.0
     alg = B * H * W * 5 * (1 + k)
-    res.append({"batch": B, "neighbours": k, "height": H, "width": W, "factor": 1.0, "depth": "plane",
+    res.append({"batch": B, "neighbours": k, "height": H, "width": W, "factor": float(env.get("FACTOR", 1.0)), "depth": env.get("DEPTH", "plane"),
                 "launches_averaged": len(c["TCC_EA0_RDREQ_sum"]), "hbm_read_bytes_per_launch": rd,
                 "hbm_write_bytes_per_launch": wr, "hbm_bytes_per_launch": rd + wr,
                 "algorithmic_bytes_per_launch": alg, "anchor_read_once_bytes": alg,
@@ -51,6 +53,6 @@ json.dump({"kernel": "pair_loss_fused_kernel", "tool": "rocprofv3 --pmc TCC_EA0_
            "workloads": res, "source": src, "source_sha256": hashlib.sha256(open(src, "rb").read()).hexdigest()},
           open(out + ".json", "w"), indent=1)
 for r in res:
-    print(r["batch"], r["neighbours"], "%dx%d" % (r["width"], r["height"]), "read %.1f MB write %.1f MB algorithmic %.1f MB ratio %.3f"
+    print(r["batch"], r["neighbours"], "%dx%d" % (r["width"], r["height"]), r["depth"], r["factor"], "read %.1f MB write %.1f MB algorithmic %.1f MB ratio %.3f"
           % (r["hbm_read_bytes_per_launch"] / 1e6, r["hbm_write_bytes_per_launch"] / 1e6, r["algorithmic_bytes_per_launch"] / 1e6, r["traffic_over_algorithmic"]))
 PY
