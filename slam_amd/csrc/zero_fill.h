@@ -25,7 +25,7 @@ __global__ void __launch_bounds__(256) zero_bytes_kernel(unsigned char* __restri
 
 inline hipError_t zero_async(void* ptr, size_t bytes, hipStream_t s) {
   if (bytes == 0) return hipSuccess;
-#ifdef SLAMHIP_ZERO_BY_MEMSET   // diagnostic build only: the memset nodes this file exists to avoid (see DESIGN.md)
+#ifdef SLAMHIP_ZERO_BY_MEMSET   // diagnostic build only: the memset nodes this file exists to avoid
   return hipMemsetAsync(ptr, 0, bytes, s);
 #endif
   size_t head = (16 - (reinterpret_cast<uintptr_t>(ptr) & 15)) & 15;
