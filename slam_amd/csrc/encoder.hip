@@ -519,6 +519,246 @@ __device__ __attribute__((aligned(256))) uint4 g_zero_line[16];   // never writt
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* global_void_ptr;
 
+// ---------------------------------------------------------------------------
+// 3x3 convolution (or data gradient) of a 64 -> 64 channel layer with the WEIGHTS HELD IN REGISTERS: the whole
+// 64 x 576 filter is 72 KB, i.e. 288 vector registers per lane as MFMA B fragments, which a wave keeps across a
+// persistent walk over pixel tiles (one wave per SIMD, 512 registers each).  Only the pixel fragments come from
+// LDS (0.5 KB of fragment reads per MFMA), the weights are read from memory once per workgroup, and the pixel
+// tiles go global -> LDS through the DMA path (no staging registers, no ds_write).
+//   A K-step is one filter row, as in the filter-row kernel above: pixels m0 - 1 .. m0 + 262 shifted by dy image
+//   rows, 264 staged rows of 128 bytes (chunk q of row R at position q ^ ((R >> 1) & 7), permuted on the source
+//   side), four LDS buffers so that the DMA loads of three steps are in flight; the three taps read the staged
+//   tile at row offsets 0, 1, 2; a tap outside the image reads a row of zeros.  Four waves stacked along the
+//   pixels, 64 x 64 outputs each; the output tile leaves through a wave-private LDS area in 16-byte stores.
+//   Needs M * 128 < 2^32 (32-bit byte offsets) and H >= 256 / W + 1 (the pixel coordinates advance by a tile).
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv3x3_c64_ws_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
+                      int H, int W, int flip, int total_tiles, float* __restrict__ stat_part) {
+  constexpr int C = 64, N = 64, ROWS = 264, BUF = ROWS * 128, OUT_AREA = 32 * 128, NBUF = 4;
+#ifdef SLAMHIP_ABL_WS     // timing-only ablations (wrong results): 1 no epilogue, 2 no DMA loads after the first three, 4 no fragment reads
+  constexpr int ABL = SLAMHIP_ABL_WS;
+#else
+  constexpr int ABL = 0;
+#endif
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NBUF * BUF + 1024];
+  // (an array of its own: accesses to it are known not to touch what the DMA loads in flight write)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds_out[4 * OUT_AREA];
+  constexpr int ZERO_OFF = NBUF * BUF;   // a row of zeros
+
+  // contiguous runs of tiles per workgroup, neighbouring runs on one XCD (the halo rows of a tile are its
+  // neighbours' rows)
+  const int nwg = gridDim.x, per = (total_tiles + nwg - 1) / nwg;
+  const int wg = (blockIdx.x & 7) * (nwg >> 3) + (blockIdx.x >> 3);
+  const int t_begin = wg * per, t_end = min(t_begin + per, total_tiles);
+  if (t_begin >= t_end) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wm = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qh = lane >> 5;
+  const unsigned int lds_base = (unsigned int)(uintptr_t)(lds_void_ptr)lds;
+  if (tid < 8) *reinterpret_cast<uint4*>(lds + ZERO_OFF + tid * 16) = make_uint4(0u, 0u, 0u, 0u);
+
+  // the filter as B fragments: weight slot e (0..8), 16-channel step kk, output half j
+  bf16x8 fb[9][4][2];
+#pragma unroll
+  for (int e = 0; e < 9; ++e)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        fb[e][kk][j] = *reinterpret_cast<const bf16x8*>(Bw + (long long)(j * 32 + (lane & 31)) * (9 * C) + e * C + kk * 16 + 8 * qh);
+
+  // requests the staged rows of filter row g of tile `tile` into buffer `buf`: piece P (8 rows, 1 KiB) = wave * 8 + j,
+  // the 33rd piece by wave 0; lane -> row 8 P + (lane >> 3), position lane & 7
+  auto issue = [&](const int tile, const int g, const int buf) {
+    int ln = lane;
+    asm volatile("" : "+v"(ln));     // (a lane's row and chunk are made again at every call: held across the tile
+                                     // loop they take registers the filter needs)
+    const int dy = (flip ? 2 - g : g) - 1;
+    const int rl = ln >> 3;
+    const int q0 = tile * 256 - 1 + dy * W + wm * 64 + rl;             // pixel of piece wave * 8, this lane's row
+    const unsigned int c_even = (unsigned int)(((ln & 7) ^ (rl >> 1)) << 4), c_odd = c_even ^ 64u;   // (R >> 1) & 7 by piece parity
+    unsigned char* dst = lds + buf * BUF + wm * 8192;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int q = min(max(q0 + 8 * j, 0), M - 1);
+      const char* src = reinterpret_cast<const char*>(A) + (size_t)(((unsigned int)q << 7) + ((j & 1) ? c_odd : c_even));
+      __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(dst + j * 1024), 16, 0, 0);
+    }
+    if (wm == 0) {
+      const int q = min(max(q0 + 256, 0), M - 1);
+      const char* src = reinterpret_cast<const char*>(A) + (size_t)(((unsigned int)q << 7) + c_even);
+      __builtin_amdgcn_global_load_lds((global_void_ptr)src, (lds_void_ptr)(dst + 32 * 1024), 16, 0, 0);
+    }
+  };
+  // waits until this wave's loads of all but the newest `newer` steps have landed (stores in flight only make
+  // the wait stricter: the counter counts them too)
+  auto wait_loads = [&](const int newer) {
+    if (newer <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (newer == 1) { if (wm == 0) asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
+    else { if (wm == 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+  };
+
+  const int n_steps = (t_end - t_begin) * 3;
+  __syncthreads();     // the row of zeros
+  issue(t_begin, 0, 0);
+  issue(t_begin, 1, 1);
+  issue(t_begin, 2, 2);
+
+  // image coordinates of this lane's two fragment rows (pixels), advanced by 256 pixels per tile
+  const int step_x = 256 % W, step_y = 256 / W;
+  int px[2], py[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long long m = (long long)t_begin * 256 + wm * 64 + i * 32 + (lane & 31);
+    const int rem = (int)(m % ((long long)H * W));
+    py[i] = rem / W;
+    px[i] = rem - py[i] * W;
+  }
+
+  int step = 0;
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int m0 = tile * 256;
+    int ln = lane;
+    asm volatile("" : "+v"(ln));     // (opaque per tile: nothing below is hoisted out of the tile loop into registers)
+    const int l31 = ln & 31, qo = ln >> 5;
+    // validity of the nine taps of the two pixels
+    unsigned int fm[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = m0 + wm * 64 + i * 32 + l31, y = py[i], x = px[i];
+      unsigned int mask = 0u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if ((unsigned)(y + t / 3 - 1) < (unsigned)H && (unsigned)(x + t % 3 - 1) < (unsigned)W) mask |= 1u << t;
+      fm[i] = m < M ? mask : 0u;
+      int nx = x + step_x, ny = y + step_y;
+      if (nx >= W) { nx -= W; ++ny; }
+      if (ny >= H) ny -= H;
+      px[i] = nx; py[i] = ny;
+    }
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+#pragma unroll
+    for (int g = 0; g < 3; ++g, ++step) {
+      // this step's rows have landed (every wave's: the barrier), and every wave has finished with the buffer
+      // that the loads issued below overwrite (it held the step before this one)
+      if (!(ABL & 2) || step < 3) wait_loads(min(n_steps - 1 - step, 2));
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();     // (a raw barrier: __syncthreads would also wait for the loads in flight)
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + 3 < n_steps && !(ABL & 2)) issue(tile + 1, g, (step + 3) & 3);
+      const unsigned int buf_base = lds_base + (unsigned int)((step & 3) * BUF);
+      // The fragment reads are written as assembly with their own waits: the compiler takes every LDS read behind a
+      // DMA load for a possible reader of what that load writes and would wait for all loads in flight (the
+      // barrier above is what orders them).
+      bf16x8 fa[2][2];
+      // per weight slot e of this filter row and fragment row i: the staged row's address (or the row of zeros when
+      // the tap lies outside the image) and the swizzled position of 16-channel step 0; step kk is position ^ (kk << 5)
+      unsigned int rb[3][2], cp[3][2];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) {
+        const int shift = flip ? 2 - e : e;
+        const int t = flip ? 8 - (g * 3 + e) : g * 3 + e;   // geometric tap of weight slot (g, e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int R = wm * 64 + i * 32 + l31 + shift;
+          const unsigned int row_addr = buf_base + (unsigned int)(R * 128), zero_addr = lds_base + (unsigned int)ZERO_OFF;
+          rb[e][i] = ((fm[i] >> t) & 1u) ? row_addr : zero_addr;
+          cp[e][i] = (unsigned int)((qo ^ ((R >> 1) & 7)) << 4);
+        }
+      }
+      auto frags = [&](const int set, const int it) {
+        const int e = it >> 2, kk = it & 3;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const unsigned int addr = (cp[e][i] ^ (unsigned int)(kk << 5)) + rb[e][i];
+          if (ABL & 4) asm volatile("; no fragment read %0 %1" : "=v"(fa[set][i]) : "v"(addr));
+          else asm volatile("ds_read_b128 %0, %1" : "=v"(fa[set][i]) : "v"(addr));
+        }
+      };
+      frags(0, 0);
+#pragma unroll
+      for (int it = 0; it < 12; ++it) {
+        // LDS reads of one wave return in order: "at most two outstanding" means that the pair read one sub-step
+        // earlier has arrived
+        if (it + 1 < 12) {
+          frags((it + 1) & 1, it + 1);
+          asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fa[it & 1][0]), "+v"(fa[it & 1][1]));
+        } else {
+          asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[it & 1][0]), "+v"(fa[it & 1][1]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[it & 1][i], fb[g * 3 + (it >> 2)][it & 3][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+
+    if (ABL & 1) {   // one store that never happens keeps the accumulators alive
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+      if (t == 12345.678f) out_bf16[tid] = (bf16)t;
+      continue;
+    }
+    // the wave's 64 x 64 outputs through its own LDS area, 32 rows of 128 bytes at a time, then 16-byte stores
+    unsigned char* oa = lds_out + wm * OUT_AREA;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = (r & 3) + 8 * (r >> 2) + 4 * qo, colc = j * 32 + l31;
+          // (chunk swizzle by row so that the 16-byte reads of a row and these 2-byte writes spread over the banks)
+          *reinterpret_cast<bf16*>(oa + row * 128 + ((((colc >> 3) ^ (row & 7)) << 4) | ((colc & 7) << 1))) = (bf16)acc[i][j][r];
+        }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const int row = v * 8 + (ln >> 3), c8 = ln & 7;
+        const int m = m0 + wm * 64 + i * 32 + row;
+        const uint4 val = *reinterpret_cast<const uint4*>(oa + row * 128 + ((c8 ^ (row & 7)) << 4));
+        if (m < M) *reinterpret_cast<uint4*>(out_bf16 + (long long)m * N + c8 * 8) = val;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (stat_part && m0 / 64 + wm < (M + 127) / 128 * 2) {
+      float* part = stat_part + ((long long)tile * 4 + wm) * 2 * N;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float sm = 0.f, sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = (float)(bf16)acc[i][j][r];
+            sm += v;
+            sq = __builtin_fmaf(v, v, sq);
+          }
+        store_column_stats(sm, sq, part, j * 32 + l31, N, ln);
+      }
+    }
+  }
+}
+
 template <int TAPS>
 __global__ void __launch_bounds__(512)
 igemm256_bf16_kernel(const bf16* __restrict__ A, const bf16* __restrict__ Bw, bf16* __restrict__ out_bf16, int M,
@@ -2461,6 +2701,24 @@ static long long launch_conv3x3(const void* act, const void* w_nk, void* out_bf1
       records += 2LL * m_small;
     }
     return records;
+  }
+  // 64 -> 64 channels with many pixels: the filter held in registers across a persistent walk over the pixel tiles,
+  // one workgroup per compute unit.  Off unless SLAMHIP_CONV_WS=1: measured at 224 x 224, batch 128 it equals the
+  // filter-row kernel (forward 717 against 720 us, data gradient 736 against 729 us) - with one wave per SIMD its
+  // epilogue, DMA issue and fragment reads do not hide behind the MFMAs (timing ablations: MFMAs and barriers alone
+  // 367 us, + epilogue 144, + DMA 137, + fragment reads 94)
+  static const bool conv_ws = [] { const char* e = getenv("SLAMHIP_CONV_WS"); return e ? atoi(e) != 0 : false; }();
+  if (conv_ws && out_bf16 && !out_f32 && N == 64 && C == 64 && M >= 128 * 1024 && M < (1LL << 25) && W >= 1 && H >= 256 / W + 1) {
+    static const int ws_grid = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8)
+        n = 256;
+      return n / 8 * 8;
+    }();
+    const int m_tiles = (int)((M + 255) / 256);
+    hipLaunchKernelGGL(conv3x3_c64_ws_kernel, dim3(ws_grid), dim3(256), 0, s, (const bf16*)act, (const bf16*)w_nk,
+                       (bf16*)out_bf16, (int)M, H, W, flip, m_tiles, stat_part);
+    return (M + 127) / 128 * 2;
   }
   // many pixels, few channels (bfloat16 output only): one K-step per filter row (SLAMHIP_IGEMM_ROW3=0: off)
   // (measured at batch 128 against the per-tap kernel: 224 x 224 x 64 -> 64 forward 940 -> 860 us, data

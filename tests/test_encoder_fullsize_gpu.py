@@ -19,7 +19,7 @@ torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FALLBACK_ENV = {"SLAMHIP_IGEMM256": "0", "SLAMHIP_IGEMM_ROW3": "0", "SLAMHIP_WGRAD_ROWS64": "0", "SLAMHIP_WGRAD256": "0",
+FALLBACK_ENV = {"SLAMHIP_IGEMM256": "0", "SLAMHIP_IGEMM_ROW3": "0", "SLAMHIP_CONV_WS": "0", "SLAMHIP_WGRAD_ROWS64": "0", "SLAMHIP_WGRAD256": "0",
                 "SLAMHIP_WGRAD_ROWGROUP": "0", "SLAM_FUSE_FIRST_BWD": "0", "SLAM_FIRST_RECOMPUTE": "0"}
 
 
@@ -118,6 +118,19 @@ def test_batch_128_each_layer_default_dispatch_against_fallback_kernels(tmp_path
     worst = {k: _rel(default[k], fallback[k]) for k in default.files}
     print("per layer, default dispatch vs fallback kernels, relative L2:", {k: round(v, 6) for k, v in worst.items()})
     bad = {k: v for k, v in worst.items() if not v < (2e-3 if k.startswith(("z_", "din_")) else 1e-3)}
+    assert not bad, bad
+
+
+def test_batch_128_weights_in_registers_kernel_against_fallback_kernels(tmp_path):
+    """The opt-in 64 -> 64 channel kernel that keeps the filter in registers (SLAMHIP_CONV_WS=1; off by default
+    because it is no faster than the filter-row kernel): forward + statistics and data gradient of conv1_2 at batch
+    128 against the general kernels on identical operands."""
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    ws = _worker("layers", str(tmp_path / "ws.npz"), {"SLAMHIP_CONV_WS": "1"})
+    fallback = _worker("layers", str(tmp_path / "fallback.npz"), FALLBACK_ENV)
+    keys = [k for k in ws.files if k.endswith("conv1_2")]
+    assert "z_conv1_2" in keys and "din_conv1_2" in keys, ws.files
+    bad = {k: _rel(ws[k], fallback[k]) for k in keys if not _rel(ws[k], fallback[k]) < 2e-3}
     assert not bad, bad
 
 
