@@ -180,8 +180,17 @@ def main():
     if world > 1 or "LOCAL_RANK" in os.environ:   # under torch.distributed.run, a group of one too
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        # (BENCH_REHEARSAL_BACKEND=gloo: a rehearsal of the several-rank control flow on a box with fewer GPUs than
+        # ranks - the ranks then share GPUs and the collectives go through gloo; never a measurement, and only with
+        # --encoder-steps 0 --train-steps 0: gloo stalls on all-reduces of GPU tensor slices)
+        rehearsal = os.environ.get("BENCH_REHEARSAL_BACKEND", "")
+        if rehearsal:
+            local = local % torch.cuda.device_count()
+            torch.cuda.set_device(local)
+            dist.init_process_group(rehearsal)
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -197,7 +206,7 @@ def main():
             ver = ".".join(str(v) for v in torch.cuda.nccl.version())
         except Exception as e:       # the version query is informational
             ver = "unknown (%s)" % type(e).__name__
-        distributed = {"backend": dist.get_backend(), "library": "RCCL (torch's nccl backend on ROCm)",
+        distributed = {"backend": dist.get_backend(), "library": "RCCL (torch's nccl backend on ROCm)" if dist.get_backend() == "nccl" else "%s (rehearsal, not RCCL)" % dist.get_backend(),
                        "rccl_ranks": int(round(float(ones.item()))), "rccl_version": ver,
                        "world_size": world, "hip": torch.version.hip}
 
