@@ -343,7 +343,18 @@ def main():
     if a.encoder_steps > 0:
         try:
             from slam_amd.network.cnn_model import timed_training_steps
-            enc = timed_training_steps(128 if world == 1 else 64, a.encoder_steps, warmup=2, seed=0, data_seed=rank)
+            enc, enc_err = None, None
+            try:
+                enc = timed_training_steps(128 if world == 1 else 64, a.encoder_steps, warmup=2, seed=0, data_seed=rank)
+            except Exception as e:
+                enc_err = e
+            if dist is not None:
+                # every rank takes the same branch below: a rank that failed does not leave the others in the collective
+                from slam_amd import distributed as dp
+                if not dp.all_ranks_ok(enc_err is None, device=dev) and enc_err is None:
+                    enc_err = RuntimeError("the encoder leg failed on another rank")
+            if enc_err is not None:
+                raise enc_err
             if dist is not None:
                 t = torch.tensor([enc["step_ms"]], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
