@@ -43,8 +43,9 @@ namespace slamhip {
 //      (colour bytes read as binary16 subnormals) with 16-byte / 8-byte global loads;
 //   C  phase 1 and phase 2 above; a tap outside the window (large parallax, a window
 //      cut at WIN_PITCH x WIN_ROWS) is gathered straight from global memory - with the
-//      certified coordinates of phase 1 where the pixel has them (a tap pair in
-//      two vector loads), in phase 2 otherwise - so the prediction never affects results.
+//      certified coordinates of phase 1 where the pixel has them (inside the same row loop: a
+//      tap pair in two vector loads, into the registers of the lane's unused window cells, blended
+//      with the window lanes), in phase 2 otherwise - so the prediction never affects results.
 // Predicates are 64-bit lane masks in scalar registers (one vector compare each,
 // combined and counted on the scalar unit).  Reduction: sums by DPP row reductions,
 // the four waves through LDS, then one float64 atomic instruction per workgroup (eight lanes:
@@ -698,8 +699,7 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
     Acc acc = {0.f, 0.f, 0.0, 0.0};
     unsigned int n_valid0 = 0, n_inb = 0, n_warp = 0, n_fast = 0;
     unsigned int n_geo = 0u;       // pixels with four non-zero depth taps (counted from the lane masks)
-    // bit r: row r of this lane is left to phase 2; bit 16 + r: certified, inside the image, taps outside the window
-    static_assert(RPW <= 16, "two bits per row in a 32-bit mask");
+    // bit r: row r of this lane is left to phase 2
     unsigned int rest_bits = 0u;
 
     PairConsts pc;
@@ -744,8 +744,10 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       // Software pipeline: row r + 1 is projected and its four cells are requested from LDS before row r
       // is blended, so that the LDS latency and the projection's dependent float64 chain overlap the
       // blend of the row before (a row's code is several basic blocks: the compiler cannot do this).
+      const unsigned int plane_bytes = 3u * (unsigned int)H * (unsigned int)W;
       struct Row {
         unsigned long long m_fast;   // lanes finished by phase 1 in this row (their taps are in the window)
+        unsigned long long m_gath;   // certified lanes inside the image whose taps were gathered from the planes instead
         float fu, fv;
         double Z;
         Cells t;
@@ -812,14 +814,14 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
 #endif
         o.t = read_cells(win, __builtin_amdgcn_inverse_ballot_w64(o.m_fast) ? idx : 0u);
-        n_fast += (unsigned int)__popcll(o.m_fast);   // these pixels count for all three masks (added at the end)
+        o.m_gath = 0ull;
         const unsigned long long m_other = m_valid0 & ~o.m_fast;
         if (m_other != 0ull) {
           // Certified pixels outside the window: floor(u) = wx0 + du and floor(v) = wy0 + dv are the
           // reference's, u and v are no integers, so "0 <= u <= W" is "0 <= floor(u) <= W - 1" and
           // "u <= W - 1" is "floor(u) <= W - 2" (coordinates too large for int32 wrap or saturate to values
           // that stay outside).  A pixel outside the image is finished here; one inside it whose taps the
-          // window does not hold, and every uncertified pixel, goes to phase 2.
+          // window does not hold gathers them below; every uncertified pixel goes to phase 2.
           const unsigned int iu = du + (unsigned int)wx0, iv = dv + (unsigned int)wy0;
           const unsigned long long m_out = m_cert & ~o.m_fast;
           const unsigned long long m_inb = m_out & __builtin_amdgcn_ballot_w64(iu < (unsigned int)W) &
@@ -830,8 +832,24 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
           n_inb += (unsigned int)__popcll(m_inb & ~m_wv);
           const unsigned long long m_unc = m_valid0 & ~m_cert;
           if (m_unc != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_unc) ? (1u << r) : 0u;
-          if (m_wv != 0ull) rest_bits |= __builtin_amdgcn_inverse_ballot_w64(m_wv) ? (0x10000u << r) : 0u;
+          if (m_wv != 0ull) {
+            // taps outside the window: the two tap pairs straight from the neighbour's planes, as loaded, into the
+            // registers of the lane's (unused) window cells; they are put into the cells' form when the row is blended
+            o.m_gath = m_wv;
+#ifdef SLAMHIP_AUDIT
+            audit_add(7, m_wv);
+#endif
+            if (__builtin_amdgcn_inverse_ballot_w64(m_wv)) {
+              const unsigned int og = iv * (unsigned int)W + iu;
+              const TapPair top = load_tap_pair(d2, c2, og, plane_bytes), bot = load_tap_pair(d2, c2, og + (unsigned int)W, plane_bytes);
+              o.t.a.x = top.dd; o.t.a.y = bot.dd;
+              o.t.b.x = top.qx; o.t.b.y = top.qy;
+              o.t.c.x = bot.qx; o.t.c.y = bot.qy;
+              o.t.e.x = top.sh | (bot.sh << 8);
+            }
+          }
         }
+        n_fast += (unsigned int)__popcll(o.m_fast | o.m_gath);   // these pixels count for all three masks (added at the end)
         return o;
       };
       Row cur = project_row(0);
@@ -839,10 +857,19 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
       for (int r = 0; r < RPW; ++r) {
         Row nxt = cur;
         if (r + 1 < RPW) nxt = project_row(r + 1);
+        if (cur.m_gath != 0ull) {
+          if (__builtin_amdgcn_inverse_ballot_w64(cur.m_gath)) {
+            const TapPair top = {cur.t.a.x, cur.t.b.x, cur.t.b.y, cur.t.e.x & 0xffu};
+            const TapPair bot = {cur.t.a.y, cur.t.c.x, cur.t.c.y, cur.t.e.x >> 8};
+            tap_pair_cells(top, cur.t.a, cur.t.b);
+            tap_pair_cells(bot, cur.t.c, cur.t.e);
+          }
+        }
+        const unsigned long long m_blend = cur.m_fast | cur.m_gath;
         // (evaluated on every lane, whatever its cells hold: the mask and its count are scalar work)
-        const unsigned long long m_geo = cur.m_fast & __builtin_amdgcn_ballot_w64(taps_nonzero(cur.t));
+        const unsigned long long m_geo = m_blend & __builtin_amdgcn_ballot_w64(taps_nonzero(cur.t));
         n_geo += (unsigned int)__popcll(m_geo);
-        if (__builtin_amdgcn_inverse_ballot_w64(cur.m_fast)) {
+        if (__builtin_amdgcn_inverse_ballot_w64(m_blend)) {
           const unsigned int a_rg = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel_rg);
           const unsigned int a_b = __builtin_amdgcn_perm(a_q[r].y, a_q[r].x, sel_b);
           blend_accumulate<UNIT>(acc, __builtin_amdgcn_inverse_ballot_w64(m_geo), cur.t, cur.fu, cur.fv, inv_factor_f,
@@ -850,81 +877,6 @@ pair_loss_fused_kernel(const FusedArgs a, const uint16_t* __restrict__ depth1, c
         }
         cur = nxt;
         __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead: more only lengthens live ranges
-      }
-      // ---- certified pixels inside the image whose taps the window does not hold (parallax beyond the window's
-      // reach): the same coordinates again - the same operations on the same values - and the four taps gathered
-      // from the neighbour's planes, a row ahead of their blend like the window reads above ----
-      if (__builtin_amdgcn_ballot_w64((rest_bits >> 16) != 0u) != 0ull) {
-        // (the per-column constants are fetched or made again: kept from phase 1 they would take twelve registers there)
-        asm volatile("" ::: "memory");
-        PairConsts pg;
-        if constexpr (K1) pg = s_pc;
-        else pg = pair_consts(p);
-        double A2 = fma(ucx, pg.kAc, fma(vcy0, pg.kAr, pg.kA0));
-        double B2 = fma(ucx, pg.kBc, fma(vcy0, pg.kBr, pg.kB0));
-        double C2 = fma(ucx, pg.kCc, fma(vcy0, pg.kCr, pg.kC0));
-        const double cxg = cam.cx - (double)(wx0 - 1) + WBIAS, cyg = cam.cy - (double)(wy0 - 1) + WBIAS;
-        struct Gather {
-          unsigned long long m;   // lanes that gather in this row
-          float fu, fv;
-          double Z;
-          unsigned int a_rgb;     // the anchor's colour bytes
-          TapPair top, bot;
-        };
-        const unsigned int o_lane = (unsigned int)row0 * (unsigned int)W + (unsigned int)colc;
-        const unsigned int plane_bytes = 3u * (unsigned int)H * (unsigned int)W;
-        // (the anchors' colours are read again - cache hits, next to their neighbours in the wave - instead of being
-        // kept from phase 1, where each row's colour registers are free once the row is blended; four bytes from the
-        // pixel's first, pulled back by one at the plane's last pixel)
-        auto gather_row = [&](const int r) -> Gather {
-          Gather g;
-          const bool need = (rest_bits >> (16 + r)) & 1u;
-          g.m = __builtin_amdgcn_ballot_w64(need);
-          g.fu = g.fv = 0.0f; g.Z = 0.0;
-          g.a_rgb = 0u;
-          g.top = g.bot = TapPair{0u, 0u, 0u, 0u};
-          if (g.m != 0ull) {
-            unsigned int du, dv;
-            coords(a_d[r], A2, B2, C2, pg.t0p, pg.t1p, pg.t2, cxg, cyg, du, dv, g.fu, g.fv, g.Z);
-            if (need) {
-              const unsigned int at = 3u * (o_lane + (unsigned int)r * (unsigned int)W), base = min(at, plane_bytes - 4u);
-              g.a_rgb = reinterpret_cast<const U32u*>(c1b + (size_t)base)->v;   // (shifted into place at its use)
-              const unsigned int o = (dv + (unsigned int)wy0) * (unsigned int)W + du + (unsigned int)wx0;
-              g.top = load_tap_pair(d2, c2, o, plane_bytes);
-              g.bot = load_tap_pair(d2, c2, o + (unsigned int)W, plane_bytes);
-            }
-          }
-          A2 += pg.kAr; B2 += pg.kBr; C2 += pg.kCr;
-          return g;
-        };
-        Gather gc = gather_row(0);
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-          Gather gn = gc;
-          if (r + 1 < RPW) gn = gather_row(r + 1);
-          if (gc.m != 0ull) {
-#ifdef SLAMHIP_AUDIT
-            audit_add(7, gc.m);
-#endif
-            Cells t;
-            tap_pair_cells(gc.top, t.a, t.b);
-            tap_pair_cells(gc.bot, t.c, t.e);
-            const unsigned long long m_geo = gc.m & __builtin_amdgcn_ballot_w64(taps_nonzero(t));
-            n_fast += (unsigned int)__popcll(gc.m);
-            n_geo += (unsigned int)__popcll(m_geo);
-            if (__builtin_amdgcn_inverse_ballot_w64(gc.m)) {
-              const unsigned int at = 3u * (o_lane + (unsigned int)r * (unsigned int)W);
-              const unsigned int rgb = gc.a_rgb >> (at + 4u > plane_bytes ? 8u : 0u);
-              const unsigned int a_rg = __builtin_amdgcn_perm(0u, rgb, 0x0c010c00u);
-              const unsigned int a_b = __builtin_amdgcn_perm(0u, rgb, 0x0c0c0c02u);
-              blend_accumulate<UNIT>(acc, __builtin_amdgcn_inverse_ballot_w64(m_geo), t, gc.fu, gc.fv, inv_factor_f,
-                                     a_rg, a_b, gc.Z);
-            }
-          }
-          gc = gn;
-          __builtin_amdgcn_sched_barrier(0);   // no more than one row ahead
-        }
-        rest_bits &= 0xffffu;
       }
     } else {
       // no certificate (constants out of range, a degenerate pose) or no window: every pixel in the image
